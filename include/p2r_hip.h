@@ -1,0 +1,148 @@
+/*
+ * p2r_hip.h -- C ABI of libp2r_hip.so, the MI355X (gfx950) implementation of
+ * the Pose2Room hot path.
+ *
+ * Drop-in boundary.  The first nine entry points have exactly the argument
+ * lists of the reference's internal `*_kernel_wrapper` launchers (the natural
+ * C ABI underneath its pybind module `pointnet2_ops._ext`), plus a trailing
+ * `hipStream_t` (passed as void*) and an int status instead of the reference's
+ * `exit(-1)` (include/cuda_utils.h:30-39).  Citations are relative to
+ * /root/reference/external/pointnet2_ops_lib/pointnet2_ops/_ext-src.
+ *
+ * Conventions
+ *   - every pointer is a device pointer into HBM; tensors are contiguous,
+ *     fp32 / int32 exactly as in the reference; index arithmetic is 32-bit
+ *     per batch row like the reference's.
+ *   - the library never allocates, never synchronises and never touches the
+ *     default stream: it enqueues on `stream` and returns.
+ *   - return value: 0 on success, a hipError_t code if a launch failed,
+ *     P2R_EINVAL for invalid sizes.  No entry point calls exit().
+ *   - gradient entry points OVERWRITE their output (they do not require the
+ *     caller to zero it, unlike the reference's atomicAdd kernels), except
+ *     where noted.
+ */
+#ifndef P2R_HIP_H
+#define P2R_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2R_OK 0
+#define P2R_EINVAL (-22)
+
+/* Library / build identification (sanity check for loaders). */
+int p2r_abi_version(void);          /* currently 1 */
+const char *p2r_build_arch(void);   /* "gfx950" */
+
+/* ---- pointnet2_ops._ext: the nine reference launchers ------------------ */
+
+/* replaces furthest_point_sampling_kernel_wrapper (src/sampling.cpp:11-13,
+ * src/sampling_gpu.cu:175-229).  dataset (b,n,3) f32; temp (b,n) f32 scratch
+ * (the reference requires it pre-filled with 1e10; this library fills it
+ * itself when it needs it and ignores it -- it may be NULL -- when n is small
+ * enough for the register-resident kernel, n <= 16384); idxs (b,m) i32.
+ * Index-exact with the reference, including its block-size dependent
+ * tie-break (see DESIGN.md "FPS tie rule"). */
+int p2r_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                float *temp, int *idxs, void *stream);
+
+/* replaces gather_points_kernel_wrapper (src/sampling.cpp:4-6,
+ * src/sampling_gpu.cu:8-30).  points (b,c,n), idx (b,npoints) -> out (b,c,npoints). */
+int p2r_gather_points(int b, int c, int n, int npoints, const float *points,
+                      const int *idx, float *out, void *stream);
+
+/* replaces gather_points_grad_kernel_wrapper (src/sampling.cpp:7-9,
+ * src/sampling_gpu.cu:34-57).  grad_out (b,c,npoints), idx (b,npoints) ->
+ * grad_points (b,c,n), overwritten. */
+int p2r_gather_points_grad(int b, int c, int n, int npoints,
+                           const float *grad_out, const int *idx,
+                           float *grad_points, void *stream);
+
+/* replaces query_ball_point_kernel_wrapper (src/ball_query.cpp:4-6,
+ * src/ball_query_gpu.cu:9-54).  new_xyz (b,m,3), xyz (b,n,3) ->
+ * idx (b,m,nsample) i32; every slot is written (rows with no neighbour are
+ * written as zeros, the value the reference's zero-initialised output keeps). */
+int p2r_ball_query(int b, int n, int m, float radius, int nsample,
+                   const float *new_xyz, const float *xyz, int *idx,
+                   void *stream);
+
+/* replaces group_points_kernel_wrapper (src/group_points.cpp:4-6,
+ * src/group_points_gpu.cu:8-39).  points (b,c,n), idx (b,npoints,nsample) ->
+ * out (b,c,npoints,nsample). */
+int p2r_group_points(int b, int c, int n, int npoints, int nsample,
+                     const float *points, const int *idx, float *out,
+                     void *stream);
+
+/* replaces group_points_grad_kernel_wrapper (src/group_points.cpp:8-10,
+ * src/group_points_gpu.cu:43-75).  grad_out (b,c,npoints,nsample) ->
+ * grad_points (b,c,n), overwritten. */
+int p2r_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                          const float *grad_out, const int *idx,
+                          float *grad_points, void *stream);
+
+/* replaces three_nn_kernel_wrapper (src/interpolate.cpp:4-5,
+ * src/interpolate_gpu.cu:9-68).  unknown (b,n,3), known (b,m,3) ->
+ * dist2 (b,n,3) f32 (squared), idx (b,n,3) i32. */
+int p2r_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                 float *dist2, int *idx, void *stream);
+
+/* replaces three_interpolate_kernel_wrapper (src/interpolate.cpp:6-8,
+ * src/interpolate_gpu.cu:72-111).  points (b,c,m), idx (b,n,3),
+ * weight (b,n,3) -> out (b,c,n). */
+int p2r_three_interpolate(int b, int c, int m, int n, const float *points,
+                          const int *idx, const float *weight, float *out,
+                          void *stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper (src/interpolate.cpp:9-12,
+ * src/interpolate_gpu.cu:116-154).  grad_out (b,c,n) -> grad_points (b,c,m),
+ * overwritten. */
+int p2r_three_interpolate_grad(int b, int c, int n, int m,
+                               const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points,
+                               void *stream);
+
+/* ---- net_utils/nn_distance.py (chamfer), /root/reference/net_utils ----- */
+
+#define P2R_NND_L2 0       /* nn_distance.py:56 */
+#define P2R_NND_L1SMOOTH 1 /* nn_distance.py:52, huber_loss :15-32 */
+#define P2R_NND_L1 2       /* nn_distance.py:54 */
+
+/* replaces nn_distance (nn_distance.py:34-61).  pc1 (B,N,C), pc2 (B,M,C) f32
+ * -> dist1 (B,N) f32, idx1 (B,N) i64, dist2 (B,M) f32, idx2 (B,M) i64; first
+ * minimal index on ties.  Any of the four outputs may be NULL. */
+int p2r_nn_distance(int B, int N, int M, int C, const float *pc1,
+                    const float *pc2, int mode, float delta, float *dist1,
+                    int64_t *idx1, float *dist2, int64_t *idx2, void *stream);
+
+/* backward of the above through both min-gathers: g1 (B,N), g2 (B,M) (either
+ * may be NULL = zero) -> grad_pc1 (B,N,C), grad_pc2 (B,M,C), overwritten,
+ * deterministic (no atomics). */
+int p2r_nn_distance_grad(int B, int N, int M, int C, const float *pc1,
+                         const float *pc2, int mode, float delta,
+                         const int64_t *idx1, const int64_t *idx2,
+                         const float *g1, const float *g2, float *grad_pc1,
+                         float *grad_pc2, void *stream);
+
+/* ---- net_utils/nms.py -------------------------------------------------- */
+
+/* replaces nms_3d_faster / nms_3d_faster_samecls (nms.py:41-77, :79-119),
+ * batched over B independent box sets.  boxes (B,K,stride) f64 rows
+ * [x1,y1,z1,x2,y2,z2,score(,cls)], stride 7 or 8; valid (B,K) u8 or NULL
+ * (all valid) selects the rows that take part (the reference's
+ * nonempty_box_mask sub-selection, ap_helper.py:216-228).
+ * Outputs: keep (B,K) u8 mask over the original rows; pick (B,K) i32 =
+ * surviving original indices in pick order (descending score), padded with
+ * -1; npick (B) i32.  pick / npick may be NULL.  K <= 1024.
+ * Equal scores are ordered as a stable ascending argsort would (the
+ * reference's np.argsort is unstable there). */
+int p2r_nms3d(int B, int K, int stride, const double *boxes,
+              const uint8_t *valid, double overlap_threshold, int old_type,
+              int same_cls, uint8_t *keep, int *pick, int *npick, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2R_HIP_H */

@@ -1,0 +1,65 @@
+"""ctypes loader for libp2r_hip.so (C ABI declared in include/p2r_hip.h).
+
+The library is built in-tree by `pose2room_amd/csrc/Makefile`
+(`__graft_entry__.build()`).  Loading fails loudly: there is no Python or CPU
+fallback for any entry point.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2r_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "p2r_hip.h")
+
+_lib = None
+
+
+class P2RLibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Names of every function the C header declares (used by the export test)."""
+    with open(header_path) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(p2r_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P2RLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C pose2room_amd/csrc`). pose2room_amd has no CPU fallback.")
+        try:
+            l = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise P2RLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        l.p2r_abi_version.restype = ctypes.c_int
+        l.p2r_build_arch.restype = ctypes.c_char_p
+        if l.p2r_abi_version() != 1:
+            raise P2RLibraryError("libp2r_hip.so ABI version mismatch")
+        for name in declared_symbols():
+            fn = getattr(l, name)
+            if name not in ("p2r_build_arch",):
+                fn.restype = ctypes.c_int
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"libp2r_hip: {what} failed with status {status}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or NULL for None)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,205 @@
+// fps.hip -- furthest point sampling for gfx950.
+//
+// Replaces furthest_point_sampling_kernel (reference
+// _ext-src/src/sampling_gpu.cu:69-229).  The reference runs one 512-thread block
+// per cloud with a 9-level shared-memory tree and 9 __syncthreads per round.
+//
+// MI355X design: the cloud lives in VGPRs for the whole kernel (PPT points per
+// lane: xyz + running min-distance), a round is PPT distance updates per lane,
+// one 64-bit wave arg-max (value bits in the high word, tie-priority in the low
+// word) and, only when a cloud spans several waves, one LDS slot exchange with
+// a single barrier.  No global traffic inside the round loop except the 12-byte
+// read of the newly picked point (LDS copy when the cloud fits).
+//
+// Tie rule (index-exact parity): the reference's winner among equal distances
+// is a function of its block size bs = opt_n_threads(n): thread tid = k % bs
+// keeps the lowest k on ties (strict >), and the halving tree lets the lower
+// slot win at every level, so across threads the tid with the smallest
+// bit-reversed value wins.  That is a total order
+//     (d2 desc, bitrev_L(k % bs) asc, k / bs asc)
+// which we encode as key = brev32(k % bs) | (k / bs)  (smaller = preferred) and
+// reduce in any tree shape we like.
+#include "p2r_common.h"
+
+namespace {
+
+__device__ __forceinline__ long long fps_pack(float d2, unsigned key) {
+  // d2 >= 0 (or the -1 "no candidate" sentinel): signed compare of the float
+  // bit pattern orders them like the float compare of the reference.
+  return ((long long)__float_as_int(d2) << 32) | (long long)(unsigned)(~key);
+}
+
+__device__ __forceinline__ unsigned fps_key(int k, int L) {
+  const unsigned bsm1 = (1u << L) - 1u;
+  return __brev((unsigned)k & bsm1) | ((unsigned)k >> L);
+}
+
+__device__ __forceinline__ int fps_unkey(unsigned key, int L) {
+  const unsigned bsm1 = (1u << L) - 1u;
+  const unsigned tid = __brev(key) & bsm1;
+  const unsigned q = (L == 0) ? key : (key & ((1u << (32 - L)) - 1u));
+  return (int)(tid + (q << L));
+}
+
+__device__ __forceinline__ long long i64max(long long a, long long b) { return a > b ? a : b; }
+
+// All-lanes max over the wave (xor butterfly; every lane ends with the result).
+__device__ __forceinline__ long long wave_max_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = i64max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Register-resident FPS: W waves per cloud, PPT points per lane, n <= 64*W*PPT.
+template <int W, int PPT, bool XYZ_IN_LDS>
+__global__ __launch_bounds__(W * 64) void fps_reg_kernel(int n, int m, int L,
+                                                         const float *__restrict__ dataset,
+                                                         int *__restrict__ idxs) {
+  constexpr int T = W * 64;
+  extern __shared__ float s_dyn[];        // XYZ_IN_LDS: n*3 floats
+  __shared__ long long s_slot[2][W > 1 ? W : 1];
+
+  const int tid = threadIdx.x;
+  const float *ds = dataset + (size_t)blockIdx.x * n * 3;
+  int *out = idxs + (size_t)blockIdx.x * m;
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  unsigned nkey[PPT];  // ~key, 0 marks "never a candidate"
+  bool live[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int k = tid + p * T;
+    const bool in = k < n;
+    const float x = in ? ds[k * 3 + 0] : 0.f;
+    const float y = in ? ds[k * 3 + 1] : 0.f;
+    const float z = in ? ds[k * 3 + 2] : 0.f;
+    px[p] = x; py[p] = y; pz[p] = z;
+    td[p] = 1e10f;
+    const float mag = (x * x) + (y * y) + (z * z);
+    // reference: `if (mag <= 1e-3) continue;` compares in double; float(1e-3) is
+    // the first float above 0.001, so the float test `mag < 1e-3f` is identical.
+    live[p] = in && !(mag < 1e-3f);
+    nkey[p] = ~fps_key(k, L);
+    if (XYZ_IN_LDS && in) {
+      s_dyn[k * 3 + 0] = x; s_dyn[k * 3 + 1] = y; s_dyn[k * 3 + 2] = z;
+    }
+  }
+  if (tid == 0) out[0] = 0;
+  if (XYZ_IN_LDS) __syncthreads();
+
+  const long long kEmpty = ((long long)__float_as_int(-1.0f) << 32) | 0xFFFFFFFFll;  // -> k = 0
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    float x1, y1, z1;
+    if (XYZ_IN_LDS) {
+      x1 = s_dyn[old * 3 + 0]; y1 = s_dyn[old * 3 + 1]; z1 = s_dyn[old * 3 + 2];
+    } else {
+      x1 = ds[old * 3 + 0]; y1 = ds[old * 3 + 1]; z1 = ds[old * 3 + 2];
+    }
+    long long best = kEmpty;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const float d = p2r_sqdist(px[p], py[p], pz[p], x1, y1, z1);
+      const float d2 = fminf(d, td[p]);
+      if (live[p]) {
+        td[p] = d2;
+        best = i64max(best, ((long long)__float_as_int(d2) << 32) | (long long)nkey[p]);
+      }
+    }
+    best = wave_max_i64(best);
+    if (W > 1) {
+      const int buf = j & 1;
+      if ((tid & 63) == 0) s_slot[buf][tid >> 6] = best;
+      __syncthreads();
+      long long r = s_slot[buf][0];
+#pragma unroll
+      for (int w = 1; w < W; ++w) r = i64max(r, s_slot[buf][w]);
+      best = r;
+    }
+    old = fps_unkey(~(unsigned)(best & 0xFFFFFFFFll), L);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// Streaming FPS for clouds that do not fit the register file: xyz re-read from
+// L2 every round, running distances in the caller's `temp` scratch.
+__global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L,
+                                                          const float *__restrict__ dataset,
+                                                          float *__restrict__ temp,
+                                                          int *__restrict__ idxs) {
+  constexpr int T = 1024, W = 16;
+  __shared__ long long s_slot[2][W];
+  const int tid = threadIdx.x;
+  const float *ds = dataset + (size_t)blockIdx.x * n * 3;
+  float *tp = temp + (size_t)blockIdx.x * n;
+  int *out = idxs + (size_t)blockIdx.x * m;
+  for (int k = tid; k < n; k += T) tp[k] = 1e10f;  // sampling.cpp:74-76
+  if (tid == 0) out[0] = 0;
+  const long long kEmpty = ((long long)__float_as_int(-1.0f) << 32) | 0xFFFFFFFFll;
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = ds[old * 3 + 0], y1 = ds[old * 3 + 1], z1 = ds[old * 3 + 2];
+    long long best = kEmpty;
+    for (int k = tid; k < n; k += T) {
+      const float x = ds[k * 3 + 0], y = ds[k * 3 + 1], z = ds[k * 3 + 2];
+      const float mag = (x * x) + (y * y) + (z * z);
+      if (mag < 1e-3f) continue;
+      const float d = p2r_sqdist(x, y, z, x1, y1, z1);
+      const float d2 = fminf(d, tp[k]);
+      tp[k] = d2;
+      best = i64max(best, fps_pack(d2, fps_key(k, L)));
+    }
+    best = wave_max_i64(best);
+    const int buf = j & 1;
+    if ((tid & 63) == 0) s_slot[buf][tid >> 6] = best;
+    __syncthreads();
+    long long r = s_slot[buf][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) r = i64max(r, s_slot[buf][w]);
+    old = fps_unkey(~(unsigned)(r & 0xFFFFFFFFll), L);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+template <int W, int PPT>
+int launch_reg(int b, int n, int m, int L, const float *dataset, int *idxs, hipStream_t st) {
+  const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
+  if (xyz_bytes <= 64 * 1024) {
+    hipLaunchKernelGGL((fps_reg_kernel<W, PPT, true>), dim3(b), dim3(W * 64), xyz_bytes, st, n, m, L,
+                       dataset, idxs);
+  } else {
+    hipLaunchKernelGGL((fps_reg_kernel<W, PPT, false>), dim3(b), dim3(W * 64), 0, st, n, m, L,
+                       dataset, idxs);
+  }
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+}  // namespace
+
+extern "C" int p2r_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                           int *idxs, void *stream) {
+  if (b < 0 || n < 0 || m < 0) return P2R_EINVAL;
+  if (b == 0 || m == 0) return P2R_OK;
+  if (n == 0) return P2R_EINVAL;
+  hipStream_t st = p2r_stream(stream);
+  const int bs = p2r_ref_opt_n_threads(n);
+  const int L = __builtin_ctz((unsigned)bs);
+  // Smallest register tiling that covers n.  One wave holds up to 512 points;
+  // larger clouds add waves (<= 16) before adding points per lane.
+  if (n <= 64) return launch_reg<1, 1>(b, n, m, L, dataset, idxs, st);
+  if (n <= 128) return launch_reg<1, 2>(b, n, m, L, dataset, idxs, st);
+  if (n <= 256) return launch_reg<1, 4>(b, n, m, L, dataset, idxs, st);
+  if (n <= 512) return launch_reg<1, 8>(b, n, m, L, dataset, idxs, st);
+  if (n <= 1024) return launch_reg<2, 8>(b, n, m, L, dataset, idxs, st);
+  if (n <= 2048) return launch_reg<4, 8>(b, n, m, L, dataset, idxs, st);
+  if (n <= 4096) return launch_reg<8, 8>(b, n, m, L, dataset, idxs, st);
+  if (n <= 8192) return launch_reg<16, 8>(b, n, m, L, dataset, idxs, st);
+  if (n <= 16384) return launch_reg<16, 16>(b, n, m, L, dataset, idxs, st);
+  if (temp == nullptr) return P2R_EINVAL;
+  hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, L, dataset, temp, idxs);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

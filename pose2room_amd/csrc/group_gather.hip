@@ -1,0 +1,179 @@
+// group_gather.hip -- index gather / scatter-add kernels for gfx950.
+//
+// Replaces group_points_kernel / group_points_grad_kernel (reference
+// _ext-src/src/group_points_gpu.cu:8-75) and gather_points_kernel /
+// gather_points_grad_kernel (src/sampling_gpu.cu:8-57).  gather_points is
+// group_points with nsample = 1, so both pairs share one implementation.
+//
+// Reference launch shape: one block per cloud, each thread walking nsample
+// indices serially and writing with stride nsample (uncoalesced), and the
+// backward does one global float atomicAdd per element.
+//
+// MI355X design
+//  forward : HBM-write bound.  A thread owns 4 consecutive (j,k) slots: one
+//            16-byte idx load, four L1/L2-resident source reads, one 16-byte
+//            coalesced store; it keeps the four indices in registers and walks
+//            a chunk of channels, so the index tensor is read once per chunk,
+//            not once per channel.
+//  backward: the destination rows of a channel chunk (GC x n floats) live in
+//            LDS; the block scatter-adds with ds_add_f32 (no HBM atomics) and
+//            writes the finished rows out coalesced, overwriting grad_points
+//            -- no zero-fill pass, no read-modify-write traffic to HBM.  Rows
+//            too long for LDS fall back to global atomics on a zeroed buffer.
+#include "p2r_common.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_CCHUNK = 16;  // channels walked per block in the forward
+
+// out[b,l,s] = points[b,l,idx[b,s]],  s in [0, S = npoints*nsample)
+__global__ __launch_bounds__(GP_THREADS) void group_fwd_kernel(
+    int c, int n, int S, int s_tiles, int c_tiles, int vec_ok, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out) {
+  int bid = blockIdx.x;
+  const int st = bid % s_tiles; bid /= s_tiles;
+  const int ct = bid % c_tiles;
+  const int batch = bid / c_tiles;
+
+  const float *p = points + (size_t)batch * c * n;
+  const int *id = idx + (size_t)batch * S;
+  float *o = out + (size_t)batch * c * S;
+
+  const int s0 = (st * GP_THREADS + threadIdx.x) * 4;
+  if (s0 >= S) return;
+  const int l0 = ct * GP_CCHUNK;
+  const int l1 = min(l0 + GP_CCHUNK, c);
+
+  if (vec_ok) {  // S % 4 == 0 and 16-byte aligned bases: whole quad in range
+    const int4 ii = *reinterpret_cast<const int4 *>(id + s0);
+#pragma unroll 4
+    for (int l = l0; l < l1; ++l) {
+      const float *row = p + (size_t)l * n;
+      float4 v;
+      v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+      *reinterpret_cast<float4 *>(o + (size_t)l * S + s0) = v;
+    }
+  } else {
+    for (int s = s0; s < min(s0 + 4, S); ++s) {
+      const int ii = id[s];
+      for (int l = l0; l < l1; ++l) o[(size_t)l * S + s] = p[(size_t)l * n + ii];
+    }
+  }
+}
+
+constexpr int GG_THREADS = 512;
+
+// grad_points[b,l,:] = sum over s of grad_out[b,l,s] scattered at idx[b,s];
+// rows of GC channels accumulated in LDS.  dynamic LDS = GC * n floats.
+__global__ __launch_bounds__(GG_THREADS) void group_grad_lds_kernel(
+    int c, int n, int S, int c_tiles, int GC, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  extern __shared__ float s_acc[];  // [GC][n]
+  const int ct = blockIdx.x % c_tiles;
+  const int batch = blockIdx.x / c_tiles;
+  const int l0 = ct * GC;
+  const int nl = min(GC, c - l0);
+
+  const float *g = grad_out + ((size_t)batch * c + l0) * S;
+  const int *id = idx + (size_t)batch * S;
+  float *gp = grad_points + ((size_t)batch * c + l0) * n;
+
+  for (int t = threadIdx.x; t < nl * n; t += GG_THREADS) s_acc[t] = 0.f;
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += GG_THREADS) {
+    const int ii = id[s];
+    for (int l = 0; l < nl; ++l) atomicAdd(&s_acc[l * n + ii], g[(size_t)l * S + s]);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nl * n; t += GG_THREADS) gp[t] = s_acc[t];
+}
+
+// Fallback for rows longer than LDS: global atomics onto a zeroed buffer.
+__global__ __launch_bounds__(GP_THREADS) void group_grad_atomic_kernel(
+    int c, int n, int S, long long total, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  for (long long t = (long long)blockIdx.x * GP_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * GP_THREADS) {
+    const int s = (int)(t % S);
+    const long long bl = t / S;  // batch * c + l
+    const int batch = (int)(bl / c);
+    const int ii = idx[(size_t)batch * S + s];
+    atomicAdd(grad_points + bl * n + ii, grad_out[t]);
+  }
+}
+
+int group_forward(int b, int c, int n, int S, const float *points, const int *idx, float *out,
+                  hipStream_t st) {
+  if (b == 0 || c == 0 || S == 0) return P2R_OK;
+  const int s_tiles = p2r_cdiv(S, GP_THREADS * 4);
+  const int c_tiles = p2r_cdiv(c, GP_CCHUNK);
+  const long long blocks = (long long)b * c_tiles * s_tiles;
+  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+  const int vec_ok = (S % 4 == 0) && (((uintptr_t)idx | (uintptr_t)out) % 16 == 0);
+  hipLaunchKernelGGL(group_fwd_kernel, dim3((unsigned)blocks), dim3(GP_THREADS), 0, st, c, n, S,
+                     s_tiles, c_tiles, vec_ok, points, idx, out);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+int group_backward(int b, int c, int n, int S, const float *grad_out, const int *idx,
+                   float *grad_points, hipStream_t st) {
+  if (b == 0 || c == 0 || n == 0) return P2R_OK;
+  const size_t row_bytes = (size_t)n * sizeof(float);
+  // Channel chunk: as many rows as fit 64 KiB of LDS (2 blocks / CU), up to 16,
+  // while keeping >= ~512 blocks in flight when the problem is large enough.
+  int gc = 16;
+  while (gc > 1 && (gc * row_bytes > 64 * 1024)) gc >>= 1;
+  while (gc > 1 && (long long)b * p2r_cdiv(c, gc) < 512 && gc > 4) gc >>= 1;
+  if (gc * row_bytes <= 64 * 1024) {
+    const int c_tiles = p2r_cdiv(c, gc);
+    const long long blocks = (long long)b * c_tiles;
+    if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+    const size_t lds = (size_t)gc * row_bytes;
+    hipLaunchKernelGGL(group_grad_lds_kernel, dim3((unsigned)blocks), dim3(GG_THREADS), lds, st, c, n,
+                       S, c_tiles, gc, grad_out, idx, grad_points);
+    P2R_LAUNCH_CHECK();
+    return P2R_OK;
+  }
+  hipError_t e = hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const long long total = (long long)b * c * S;
+  if (total == 0) return P2R_OK;
+  const int blocks = (int)std::min<long long>(p2r_cdiv(total, GP_THREADS), 256 * 16);
+  hipLaunchKernelGGL(group_grad_atomic_kernel, dim3(blocks), dim3(GP_THREADS), 0, st, c, n, S, total,
+                     grad_out, idx, grad_points);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+}  // namespace
+
+extern "C" int p2r_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                const int *idx, float *out, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return P2R_EINVAL;
+  if ((long long)npoints * nsample > 0x7fffffffLL) return P2R_EINVAL;
+  return group_forward(b, c, n, npoints * nsample, points, idx, out, p2r_stream(stream));
+}
+
+extern "C" int p2r_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                     const float *grad_out, const int *idx, float *grad_points,
+                                     void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return P2R_EINVAL;
+  if ((long long)npoints * nsample > 0x7fffffffLL) return P2R_EINVAL;
+  return group_backward(b, c, n, npoints * nsample, grad_out, idx, grad_points, p2r_stream(stream));
+}
+
+extern "C" int p2r_gather_points(int b, int c, int n, int npoints, const float *points,
+                                 const int *idx, float *out, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return P2R_EINVAL;
+  return group_forward(b, c, n, npoints, points, idx, out, p2r_stream(stream));
+}
+
+extern "C" int p2r_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                      const int *idx, float *grad_points, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0) return P2R_EINVAL;
+  return group_backward(b, c, n, npoints, grad_out, idx, grad_points, p2r_stream(stream));
+}

@@ -1,0 +1,43 @@
+// p2r_common.h -- shared device/host helpers for libp2r_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2r_hip.h"
+
+// Parity rule: every distance / interpolation expression that the oracle
+// (oracle/p2r_oracle.c) evaluates in source order must round identically here,
+// so contraction of a*b+c into fma is disabled for all parity-critical code.
+// Kernels that WANT fused multiply-add (MFMA tiles, fmaf) ask for it explicitly.
+#pragma clang fp contract(off)
+
+#define P2R_WAVE 64
+
+#define P2R_LAUNCH_CHECK()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+static inline hipStream_t p2r_stream(void *s) { return (hipStream_t)s; }
+
+// include/cuda_utils.h:15-19 of the reference: the block size its kernels are
+// launched with.  Only the FPS tie rule depends on it.
+static inline int p2r_ref_opt_n_threads(int work_size) {
+  if (work_size <= 0) return 1;
+  const int pow_2 = (int)(__builtin_log((double)work_size) / __builtin_log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+static inline int p2r_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Squared distance exactly as the reference writes it:
+// (a-b)*(a-b) + (c-d)*(c-d) + (e-f)*(e-f), left-to-right, no contraction.
+__device__ __forceinline__ float p2r_sqdist(float ax, float ay, float az,
+                                            float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return dx * dx + dy * dy + dz * dz;
+}
