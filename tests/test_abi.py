@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol the
+header declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from pose2room_amd import _lib
+
+
+def test_library_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    # in-tree, next to the package, so the GPU-side loader sees it
+    assert os.path.dirname(_lib.LIB_PATH).endswith("pose2room_amd")
+
+
+def test_header_symbols_all_exported():
+    names = _lib.declared_symbols()
+    assert "p2r_ball_query" in names and "p2r_furthest_point_sampling" in names
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(l, n)]
+    assert not missing, f"declared in include/p2r_hip.h but not exported: {missing}"
+
+
+def test_abi_identity():
+    l = _lib.lib()
+    assert l.p2r_abi_version() == 1
+    assert l.p2r_build_arch() == b"gfx950"
+
+
+def test_reference_launcher_names_are_cited():
+    """every _ext entry point cites the reference launcher it replaces"""
+    text = open(_lib.HEADER_PATH).read()
+    for wrapper in ["furthest_point_sampling_kernel_wrapper", "gather_points_kernel_wrapper",
+                    "gather_points_grad_kernel_wrapper", "query_ball_point_kernel_wrapper",
+                    "group_points_kernel_wrapper", "group_points_grad_kernel_wrapper",
+                    "three_nn_kernel_wrapper", "three_interpolate_kernel_wrapper",
+                    "three_interpolate_grad_kernel_wrapper"]:
+        assert wrapper in text
+    assert len(re.findall(r"src/[a-z_]+\.(?:cpp|cu):\d+", text)) >= 18
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(_lib.LIB_PATH))
+    bad = []
+    for d, _, files in os.walk(os.path.join(root, "pose2room_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(os.path.join(d, f))
+    assert not bad, f"product code must not import the oracle: {bad}"
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from pose2room_amd.pointnet2_ops import _ext
+    from pose2room_amd.net_utils.nn_distance import nn_distance
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 4, 3), 0.3, 4)
+    with pytest.raises(RuntimeError):
+        nn_distance(torch.zeros(1, 2, 3), torch.zeros(1, 4, 3))

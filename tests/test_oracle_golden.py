@@ -1,0 +1,156 @@
+"""CPU: the oracle against the committed golden vectors.
+
+G1/G2 were produced by the imported reference Python (tests/golden/make_golden.py),
+so these tests pin the oracle's nn_distance / NMS to the reference.  G6 pins the
+restatement of the nine _ext kernels against regressions, and the property tests
+below check it against independent brute-force definitions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_g1_nn_distance_matches_reference(oracle):
+    z = np.load(os.path.join(G, "g1_nn_distance.npz"))
+    for name in ("demo", "vote", "assign", "center"):
+        a = torch.from_numpy(z[f"{name}_pc1"]); q = torch.from_numpy(z[f"{name}_pc2"])
+        w1 = torch.from_numpy(z[f"{name}_w1"]); w2 = torch.from_numpy(z[f"{name}_w2"])
+        for mode, kw in {"l2": {}, "l1smooth": {"l1smooth": True}, "l1": {"l1": True}}.items():
+            d1, i1, d2, i2 = oracle.nn_distance(a, q, **kw)
+            assert np.array_equal(d1.numpy(), z[f"{name}_{mode}_dist1"])
+            assert np.array_equal(i1.numpy(), z[f"{name}_{mode}_idx1"])
+            assert np.array_equal(d2.numpy(), z[f"{name}_{mode}_dist2"])
+            assert np.array_equal(i2.numpy(), z[f"{name}_{mode}_idx2"])
+            ga, gq = oracle.nn_distance_grad(a, q, i1, i2, w1, w2, **kw)
+            np.testing.assert_allclose(ga.numpy(), z[f"{name}_{mode}_grad1"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(gq.numpy(), z[f"{name}_{mode}_grad2"], rtol=1e-5, atol=1e-6)
+
+
+def test_g1_demo_known_answer(oracle):
+    """The reference demo's check (nn_distance.py:63-94): torch result == NumPy double loop."""
+    z = np.load(os.path.join(G, "g1_nn_distance.npz"))
+    a, q = z["demo_pc1"][0].astype(np.float64), z["demo_pc2"][0].astype(np.float64)
+    dist = ((a[:, None, :] - q[None, :, :]) ** 2).sum(-1)
+    d1, i1, d2, i2 = oracle.nn_distance(torch.from_numpy(z["demo_pc1"]), torch.from_numpy(z["demo_pc2"]))
+    np.testing.assert_allclose(d1[0].numpy(), dist.min(1), rtol=1e-6)
+    assert np.array_equal(i1[0].numpy(), dist.argmin(1))
+    np.testing.assert_allclose(d2[0].numpy(), dist.min(0), rtol=1e-6)
+    assert np.array_equal(i2[0].numpy(), dist.argmin(0))
+
+
+def test_g2_nms_matches_reference(oracle):
+    z = np.load(os.path.join(G, "g2_nms.npz"))
+    for K in (1, 2, 16, 128, 300):
+        boxes = z[f"boxes_{K}"]
+        assert np.array_equal(boxes, cases.random_boxes(K, seed=K))  # builder is stable
+        for thr in (0.10, 0.25):
+            for old in (False, True):
+                tag = f"{K}_{int(thr * 100)}_{int(old)}"
+                assert oracle.nms_3d(boxes[:, :7], thr, old) == z[f"pick_{tag}"].tolist()
+                assert oracle.nms_3d(boxes, thr, old, True) == z[f"pickcls_{tag}"].tolist()
+
+
+def test_g6_ext_ops_stable(oracle):
+    z = np.load(os.path.join(G, "g6_ext_ops.npz"))
+    E = oracle.OracleExt
+    for (b, n, m, kind, seed) in cases.FPS_CASES:
+        key = f"fps_{b}_{n}_{m}_{kind}_{seed}"
+        if key in z:
+            assert np.array_equal(E.furthest_point_sampling(cases.cloud(b, n, seed, kind), m).numpy(), z[key])
+    for (b, n, m, radius, nsample, kind, seed) in cases.BALL_CASES:
+        xyz = cases.cloud(b, n, seed, kind)
+        got = E.ball_query(cases.centres_from(xyz, m, seed), xyz, radius, nsample).numpy()
+        assert np.array_equal(got, z[f"ball_{b}_{n}_{m}_{nsample}_{kind}_{seed}"])
+
+
+# ---- independent definitions (property tests of the restatement) -------------
+
+def _fps_bruteforce(xyz, m):
+    """FPS from first principles for clouds without ties and without skipped points."""
+    n = xyz.shape[0]
+    d = np.full(n, 1e10, dtype=np.float32)
+    out = [0]
+    for _ in range(1, m):
+        p = xyz[out[-1]]
+        diff = (xyz - p).astype(np.float32)
+        dist = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        d = np.minimum(d, dist.astype(np.float32))
+        out.append(int(np.argmax(d)))
+    return out
+
+
+def test_fps_against_bruteforce(oracle):
+    xyz = cases.cloud(2, 300, 77) + 5.0  # away from the |p|^2 <= 1e-3 skip ball, no exact ties
+    got = oracle.OracleExt.furthest_point_sampling(xyz, 64).numpy()
+    for b in range(2):
+        assert got[b].tolist() == _fps_bruteforce(xyz[b].numpy(), 64)
+
+
+def test_fps_tie_rule_is_bit_reversed_thread_order(oracle):
+    """n=512 -> block 512, one point per thread; among exactly tied candidates the
+    reference's tree picks the smallest bit-reversed thread id."""
+    n = 512
+    xyz = torch.zeros(1, n, 3)
+    xyz[0, :, 0] = 10.0          # everything sits on one point ...
+    xyz[0, 3] = torch.tensor([11.0, 0, 0])    # ... except two points equally far from point 0
+    xyz[0, 258] = torch.tensor([9.0, 0, 0])
+    got = oracle.OracleExt.furthest_point_sampling(xyz, 2).numpy()[0]
+    assert got.tolist() == [0, 258]   # bitrev9(258)=129 < bitrev9(3)=384
+
+
+def test_fps_skips_points_near_origin(oracle):
+    xyz = cases.cloud(1, 64, 5) + 3.0
+    xyz[0, 10] = torch.tensor([0.01, 0.01, 0.01])   # |p|^2 = 3e-4 <= 1e-3: never selected
+    got = oracle.OracleExt.furthest_point_sampling(xyz, 64).numpy()[0]
+    assert 10 not in got[1:].tolist()
+    allz = torch.zeros(1, 16, 3)
+    assert oracle.OracleExt.furthest_point_sampling(allz, 5).numpy().tolist() == [[0] * 5]
+
+
+def test_ball_query_against_definition(oracle):
+    xyz = cases.cloud(2, 200, 9)
+    new_xyz = cases.centres_from(xyz, 30, 9)
+    r, ns = 0.7, 8
+    got = oracle.OracleExt.ball_query(new_xyz, xyz, r, ns).numpy()
+    for b in range(2):
+        for j in range(30):
+            d = xyz[b] - new_xyz[b, j]
+            # new - p vs p - new differ only in sign before squaring
+            d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).numpy()
+            hits = np.nonzero(d2 < np.float32(r) * np.float32(r))[0][:ns].tolist()
+            want = (hits + [hits[0]] * (ns - len(hits))) if hits else [0] * ns
+            assert got[b, j].tolist() == want
+
+
+def test_three_nn_against_sort(oracle):
+    unknown = cases.cloud(1, 50, 1); known = cases.cloud(1, 40, 2)
+    d2, idx = oracle.OracleExt.three_nn(unknown, known)
+    full = ((unknown[0, :, None, :] - known[0, None, :, :]) ** 2).sum(-1)
+    want = torch.topk(full, 3, dim=1, largest=False)
+    assert torch.equal(idx[0].long(), want.indices)
+    torch.testing.assert_close(d2[0], want.values, rtol=1e-6, atol=1e-7)
+    d2, idx = oracle.OracleExt.three_nn(unknown, known[:, :2].contiguous())
+    assert torch.isinf(d2[..., 2]).all() and (idx[..., 2] == 0).all()   # m < 3
+
+
+def test_group_gather_roundtrip(oracle):
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(2, 6, 50, generator=g)
+    idx = torch.randint(0, 50, (2, 9, 4), generator=g, dtype=torch.int32)
+    out = oracle.OracleExt.group_points(pts, idx)
+    want = torch.gather(pts.unsqueeze(2).expand(2, 6, 9, 50), 3, idx.long().unsqueeze(1).expand(2, 6, 9, 4))
+    assert torch.equal(out, want)
+    go = torch.randn(2, 6, 9, 4, generator=g)
+    grad = oracle.OracleExt.group_points_grad(go, idx, 50)
+    ref = torch.zeros(2, 6, 50).scatter_add_(2, idx.long().view(2, 1, 36).expand(2, 6, 36), go.view(2, 6, 36))
+    torch.testing.assert_close(grad, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_opt_n_threads(oracle):
+    f = oracle.lib().p2r_oracle_opt_n_threads
+    assert [f(w) for w in (1, 2, 3, 7, 8, 100, 511, 512, 513, 54272)] == [1, 2, 2, 4, 8, 64, 256, 512, 512, 512]
