@@ -1,0 +1,136 @@
+"""Detection loss (mirror of the reference's models/loss.py:8-189).
+
+total = 10*vote + 5*objectness + 10*center + 10*size + 10*heading + sem_cls
+(loss.py:167).  All three `nn_distance` call sites run on the HIP kernel; the
+reference's per-sample Python loop for the proposal->GT assignment
+(loss.py:127-131) is one batched launch here: padded GT rows are pushed out to a
+far sentinel so the minimum runs over the valid prefix only, which yields the
+same dist1 / ind1 for every sample that has at least one GT box.
+"""
+import torch
+from torch import nn
+
+from ..net_utils.nn_distance import nn_distance, huber_loss
+from .registers import LOSSES
+
+FAR_THRESHOLD = 0.6
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3                      # GT votes per joint
+OBJECTNESS_CLS_WEIGHTS = [0.1, 0.9]     # larger weight on positive objectness
+_FAR_AWAY = 1.0e18                      # sentinel coordinate of a padded GT row (squared: 1e36 < f32 max)
+
+criterion_sem_cls = nn.CrossEntropyLoss(reduction='none')
+
+
+class BaseLoss(object):
+    def __init__(self, weight=1, device=0, cfg=None):
+        self.weight = weight
+        self.device = device
+        self.origin_joint_id = cfg.dataset_config.origin_joint_id
+
+
+@LOSSES.register_module
+class Null(BaseLoss):
+    """For modules whose loss is computed elsewhere."""
+    def __call__(self, loss):
+        return self.weight * torch.mean(loss)
+
+
+@LOSSES.register_module
+class BoxNetDetectionLoss(BaseLoss):
+    def __init__(self, weight, device, cfg=None):
+        super().__init__(weight, device, cfg)
+        self.objectness_criterion = nn.CrossEntropyLoss(
+            torch.Tensor(OBJECTNESS_CLS_WEIGHTS).to(self.device), reduction='none')
+
+    # loss.py:42-88
+    def compute_box_and_sem_cls_loss(self, est_data, gt_data, meta_data, config):
+        object_assignment = meta_data['object_assignment']
+        objectness_label = meta_data['objectness_label'].float()
+        n_pos = torch.sum(objectness_label) + 1e-6
+        box_label_mask = gt_data['box_label_mask']
+
+        # centre: chamfer against ALL max_gt slots, zero padding included (only dist2 is masked)
+        dist1, _, dist2, _ = nn_distance(est_data['center'], gt_data['center_label'])
+        centroid_reg_loss1 = torch.sum(dist1 * objectness_label) / n_pos
+        centroid_reg_loss2 = torch.sum(dist2 * box_label_mask) / (torch.sum(box_label_mask) + 1e-6)
+        center_loss = (centroid_reg_loss1 + centroid_reg_loss2) / 2.
+
+        gt_size = torch.gather(gt_data['size'], 1, object_assignment.unsqueeze(-1).repeat(1, 1, 3))
+        size_loss = torch.mean(huber_loss(est_data['size'] - gt_size, delta=1.0), -1)
+        size_loss = torch.sum(size_loss * objectness_label) / n_pos
+
+        gt_heading = torch.gather(gt_data['heading'], 1, object_assignment.unsqueeze(-1).repeat(1, 1, 2))
+        heading_loss = torch.mean(huber_loss(est_data['heading'] - gt_heading, delta=1.0), -1)
+        heading_loss = torch.sum(heading_loss * objectness_label) / n_pos
+
+        gt_cls_label = torch.gather(gt_data['sem_cls_label'], 1, object_assignment)
+        sem_cls_loss = criterion_sem_cls(est_data['sem_cls_scores'].transpose(2, 1), gt_cls_label)
+        sem_cls_loss = torch.sum(sem_cls_loss * objectness_label) / n_pos
+        return center_loss, size_loss, heading_loss, sem_cls_loss
+
+    # loss.py:90-115
+    def compute_vote_loss(self, est_data, gt_data):
+        j0 = self.origin_joint_id
+        batch_size, num_seed, num_joints = est_data['seed_skeleton'].shape[:3]
+        vote_xyz = est_data['vote_xyz']
+        seed_inds = est_data['seed_inds'].long()
+
+        seed_gt_votes_mask = torch.gather(gt_data['vote_label_mask'][..., j0], 1, seed_inds)
+        seed_gt_votes = torch.gather(gt_data['vote_label'][:, :, j0], 1,
+                                     seed_inds.view(batch_size, num_seed, 1).repeat(1, 1, 3 * GT_VOTE_FACTOR))
+        seed_gt_votes = seed_gt_votes.view(batch_size, num_seed, GT_VOTE_FACTOR, 3)
+        seed_gt_votes = est_data['seed_skeleton'][:, :, [j0]] + seed_gt_votes
+
+        # which of the 3 GT votes is closest to any joint of the seed skeleton
+        _, _, dist2, ind2 = nn_distance(seed_gt_votes.view(batch_size * num_seed, GT_VOTE_FACTOR, 3),
+                                        est_data['seed_skeleton'].reshape(batch_size * num_seed, num_joints, 3))
+        vote_argmin = torch.gather(ind2, dim=1, index=dist2.argmin(-1).unsqueeze(-1)).view(batch_size, num_seed, 1)
+        seed_gt_votes = torch.gather(seed_gt_votes, 2, vote_argmin.unsqueeze(-1).repeat(1, 1, 1, 3)).squeeze(2)
+
+        vote_loss = torch.mean(huber_loss(vote_xyz - seed_gt_votes, delta=1.0), -1)
+        mask = seed_gt_votes_mask.float()
+        return torch.sum(vote_loss * mask) / (torch.sum(mask) + 1e-6)
+
+    # loss.py:117-150
+    def compute_correspondence(self, est_data, gt_data):
+        aggregated_vote_xyz = est_data['aggregated_vote_xyz']
+        gt_center = gt_data['center_label'][:, :, 0:3]
+        valid = gt_data['box_label_mask'] > 0
+        # batched form of the reference's per-sample nn_distance over per_gt_center[per_mask > 0]
+        masked_center = torch.where(valid.unsqueeze(-1), gt_center, torch.full_like(gt_center, _FAR_AWAY))
+        dist1, object_assignment, _, _ = nn_distance(aggregated_vote_xyz.detach(), masked_center)
+
+        B, K = aggregated_vote_xyz.shape[0], aggregated_vote_xyz.shape[1]
+        euclidean_dist1 = torch.sqrt(dist1 + 1e-6)
+        objectness_label = torch.zeros((B, K), dtype=torch.long).to(self.device)
+        objectness_mask = torch.zeros((B, K)).to(self.device)
+        objectness_label[euclidean_dist1 < NEAR_THRESHOLD] = 1
+        objectness_mask[euclidean_dist1 < NEAR_THRESHOLD] = 1
+        objectness_mask[euclidean_dist1 > FAR_THRESHOLD] = 1
+
+        objectness_loss = self.objectness_criterion(est_data['objectness_scores'].transpose(2, 1), objectness_label)
+        objectness_loss = torch.sum(objectness_loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
+        return object_assignment, objectness_loss, objectness_label, objectness_mask
+
+    # loss.py:152-189
+    def __call__(self, est_data, gt_data, dataset_config):
+        vote_loss = self.compute_vote_loss(est_data, gt_data)
+        object_assignment, objectness_loss, objectness_label, objectness_mask = \
+            self.compute_correspondence(est_data, gt_data)
+        meta_data = {'object_assignment': object_assignment, 'objectness_label': objectness_label}
+        center_loss, size_loss, heading_loss, sem_cls_loss = \
+            self.compute_box_and_sem_cls_loss(est_data, gt_data, meta_data, dataset_config)
+        loss = 10 * vote_loss + 5 * objectness_loss + 10 * center_loss + 10 * size_loss + \
+            10 * heading_loss + sem_cls_loss
+
+        total = objectness_label.shape[0] * objectness_label.shape[1]
+        pos_ratio = torch.sum(objectness_label.float().to(self.device)) / float(total)
+        neg_ratio = torch.sum(objectness_mask.float()) / float(total) - pos_ratio
+        obj_pred_val = torch.argmax(est_data['objectness_scores'], 2)
+        obj_acc = torch.sum((obj_pred_val == objectness_label.long()).float() * objectness_mask) / (
+            torch.sum(objectness_mask) + 1e-6)
+        return {'total': loss, 'vote_loss': vote_loss, 'objectness_loss': objectness_loss,
+                'center_loss': center_loss, 'size_loss': size_loss, 'heading_loss': heading_loss,
+                'sem_cls_loss': sem_cls_loss, 'pos_ratio': pos_ratio, 'neg_ratio': neg_ratio,
+                'obj_acc': obj_acc}

@@ -1,0 +1,159 @@
+"""Skeleton graph and spatial-temporal graph-convolution block.
+
+Host-side mirror of the reference's models/p2rnet/modules/stgcn_layers.py for
+what P2RNet instantiates: `Graph('virtualroom', 'spatial', max_hop=5)` (:69-233),
+`ConvTemporalGraphical` (:10-67) and `st_gcn_block` (:362-439).  Parameter names
+(`gcn.conv`, `tcn.{0,2,3}`) match the reference `state_dict`.
+"""
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+# 53-joint VirtualHome skeleton: (child, parent) bones, stgcn_layers.py:151-161
+_VIRTUALROOM_BONES = [
+    (0, 1), (1, 3), (3, 5), (5, 19), (0, 2), (2, 4), (4, 6), (6, 20), (0, 7), (7, 8), (8, 9),
+    (9, 10), (10, 21), (10, 22), (8, 11), (11, 13), (13, 15), (15, 17), (8, 12), (12, 14),
+    (14, 16), (16, 18), (17, 23), (23, 24), (24, 25), (17, 26), (26, 27), (27, 28), (17, 29),
+    (29, 30), (30, 31), (17, 32), (32, 33), (33, 34), (17, 35), (35, 36), (36, 37), (18, 38),
+    (38, 39), (39, 40), (18, 41), (41, 42), (42, 43), (18, 44), (44, 45), (45, 46), (18, 47),
+    (47, 48), (48, 49), (18, 50), (50, 51), (51, 52)]
+
+_LAYOUTS = {'virtualroom': dict(num_node=53, bones=_VIRTUALROOM_BONES, center=0)}
+
+
+def hop_distance(num_node, edges, max_hop):
+    """All-pairs hop count by BFS, inf beyond max_hop (same result as the
+    reference's matrix-power construction, stgcn_layers.py:208-220)."""
+    nbr = [[] for _ in range(num_node)]
+    for i, j in edges:
+        if i != j:
+            nbr[i].append(j)
+            nbr[j].append(i)
+    hop = np.full((num_node, num_node), np.inf)
+    for s in range(num_node):
+        hop[s, s] = 0
+        dq = deque([s])
+        while dq:
+            u = dq.popleft()
+            if hop[s, u] >= max_hop:
+                continue
+            for v in nbr[u]:
+                if np.isinf(hop[s, v]):
+                    hop[s, v] = hop[s, u] + 1
+                    dq.append(v)
+    return hop
+
+
+class Graph:
+    """Adjacency stack `A (K, V, V)` float64 for a skeleton layout.
+
+    strategy 'spatial': per hop h, entries with hop_dis == h are split by
+    distance to the centre joint into root+closer and further sets (K = 1 + 2*max_hop);
+    'uniform' and 'distance' as in the reference (stgcn_layers.py:163-205)."""
+
+    def __init__(self, layout='virtualroom', strategy='spatial', max_hop=5, dilation=1):
+        if layout not in _LAYOUTS:
+            raise ValueError("Do Not Exist This Layout.")
+        spec = _LAYOUTS[layout]
+        self.max_hop, self.dilation = max_hop, dilation
+        self.num_node, self.center = spec['num_node'], spec['center']
+        self.edge = [(i, i) for i in range(self.num_node)] + list(spec['bones'])
+        self.hop_dis = hop_distance(self.num_node, self.edge, max_hop)
+        self.A = self._adjacency(strategy)
+
+    def _adjacency(self, strategy):
+        V = self.num_node
+        hops = list(range(0, self.max_hop + 1, self.dilation))
+        reach = np.zeros((V, V))
+        for h in hops:
+            reach[self.hop_dis == h] = 1
+        col = reach.sum(0)
+        inv = np.zeros(V)
+        inv[col > 0] = col[col > 0] ** (-1)
+        norm = reach * inv[None, :]          # A . D^-1 (column normalisation)
+        if strategy == 'uniform':
+            return norm[None]
+        if strategy == 'distance':
+            return np.stack([np.where(self.hop_dis == h, norm, 0.0) for h in hops])
+        if strategy == 'spatial':
+            dc = self.hop_dis[:, self.center]
+            same = dc[:, None] == dc[None, :]        # [j, i]: j and i equally far from the centre
+            closer = dc[:, None] > dc[None, :]       # row joint j further from centre than column joint i
+            planes = []
+            for h in hops:
+                at_h = self.hop_dis == h             # symmetric, so [j,i] == [i,j]
+                root = np.where(at_h & same, norm, 0.0)
+                close = np.where(at_h & closer, norm, 0.0)
+                further = np.where(at_h & ~same & ~closer, norm, 0.0)
+                if h == 0:
+                    planes.append(root)
+                else:
+                    planes.append(root + close)
+                    planes.append(further)
+            return np.stack(planes)
+        raise ValueError("Do Not Exist This Strategy")
+
+
+class ConvTemporalGraphical(nn.Module):
+    """1x1 conv to K*C_out channels followed by the K-way graph contraction
+    'nkctv,kvw->nctw' (stgcn_layers.py:10-67).  forward(x (N,C,T,V), A (K,V,V))."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, t_kernel_size=1, t_stride=1,
+                 t_padding=0, t_dilation=1, bias=True):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.out_channels = out_channels
+        self.conv = nn.Conv2d(in_channels, out_channels * kernel_size, kernel_size=(t_kernel_size, 1),
+                              padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
+                              bias=bias)
+
+    def forward(self, x, A):
+        assert A.size(0) == self.kernel_size
+        y = self.conv(x)
+        n, kc, t, v = y.size()
+        y = y.view(n, self.kernel_size, kc // self.kernel_size, t, v)
+        z = torch.einsum('nkctv,kvw->nctw', (y, A))
+        return z.contiguous(), A
+
+
+def _zero(x):
+    return 0
+
+
+def _iden(x):
+    return x
+
+
+class st_gcn_block(nn.Module):
+    """gcn -> BN -> ReLU -> temporal (k,1) conv -> BN -> dropout, plus residual,
+    then ReLU (stgcn_layers.py:362-439)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dropout=0, residual=True):
+        super().__init__()
+        assert len(kernel_size) == 2 and kernel_size[0] % 2 == 1
+        padding = ((kernel_size[0] - 1) // 2, 0)
+        self.gcn = ConvTemporalGraphical(in_channels, out_channels, kernel_size[1])
+        self.tcn = nn.Sequential(
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, (kernel_size[0], 1), (stride, 1), padding),
+            nn.BatchNorm2d(out_channels),
+            nn.Dropout(dropout, inplace=True),
+        )
+        if not residual:
+            self.residual = _zero
+        elif in_channels == out_channels and stride == 1:
+            self.residual = _iden
+        else:
+            self.residual = nn.Sequential(
+                nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1)),
+                nn.BatchNorm2d(out_channels))
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x, A):
+        res = self.residual(x)
+        x, A = self.gcn(x, A)
+        x = self.tcn(x) + res
+        return self.relu(x), A

@@ -65,3 +65,45 @@ def random_boxes(K, seed, stride=8, ncls=3):
     cls = rng.integers(0, ncls, (K, 1)).astype(np.float64)
     b = np.concatenate([c - s / 2, c + s / 2, score[:, None], cls], 1)
     return np.ascontiguousarray(b[:, :stride])
+
+
+def fill_weights(net):
+    """Deterministic, seed-free weight rule applied identically to the reference
+    model (when the fixtures are generated) and to ours (when they are checked):
+    every floating tensor of the state_dict becomes a scaled sine of its element
+    index, with fan-in scaling for conv weights so activations stay O(1).  The
+    adjacency buffer `A` and integer buffers are left alone."""
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, name in enumerate(sorted(sd.keys())):
+            t = sd[name]
+            if not t.is_floating_point() or name.endswith('.A') or name == 'backbone.A':
+                continue
+            n = t.numel()
+            base = torch.sin(torch.arange(n, dtype=torch.float64) * (0.7 + 0.013 * k) + k)
+            if name.endswith('running_var'):
+                v = 1.0 + 0.5 * base.abs()
+            elif name.endswith('running_mean'):
+                v = 0.1 * base
+            elif 'batchnorm.weight' in name or name.endswith('tcn.0.weight') or name.endswith('tcn.3.weight'):
+                v = 1.0 + 0.1 * base
+            elif 'edge_importance' in name:
+                v = 1.0 + 0.1 * base
+            elif name.endswith('log_sigma'):
+                v = 0.1 * base - 1.0
+            elif name.endswith('mdn.mu'):
+                v = 0.5 * base
+            elif name.endswith('bias'):
+                v = 0.1 * base
+            elif t.dim() > 1:
+                fan_in = t[0].numel()
+                v = base * (1.7 / fan_in ** 0.5)
+            else:
+                v = 0.1 * base
+            t.copy_(v.view_as(t).to(t.dtype))
+    return net
+
+
+def state_checksum(net):
+    sd = net.state_dict()
+    return float(sum(v.double().abs().sum() for k, v in sd.items() if v.is_floating_point()))

@@ -1,0 +1,154 @@
+"""CPU: our host model (pose2room_amd.p2rnet) against golden vectors captured from
+the imported reference (tests/golden/make_model_golden.py).  The pointnet2 ops
+and nn_distance run on the CPU oracle here (oracle.cpu_backend.cpu_ops); the GPU
+twin of this file (test_model_gpu.py) runs the same checks on the HIP path.
+
+Tolerance: fp32 outputs within 1e-4 (north star); index outputs exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+G = os.path.join(os.path.dirname(__file__), "golden", "g345_model.npz")
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def build(mode, num_frames, device='cpu', **test_over):
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    cfg = P2RConfig(default_config(mode, data={'num_frames': num_frames}, test=test_over), device=device)
+    torch.manual_seed(0); np.random.seed(0)
+    net = METHODS.get('P2RNet')(cfg)
+    cases.fill_weights(net)
+    return net, cfg
+
+
+def check_endpoints(z, tag, ep):
+    for k in ['seed_inds', 'aggregated_vote_inds']:
+        assert np.array_equal(ep[k].cpu().numpy(), z[f'{tag}_{k}']), k
+    for k in ['aggregated_vote_xyz', 'vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores']:
+        got = ep[k].detach().cpu().numpy()
+        assert got.dtype == z[f'{tag}_{k}'].dtype, (k, got.dtype)
+        np.testing.assert_allclose(got, z[f'{tag}_{k}'], err_msg=k, **TOL)
+    for k in ['seed_features', 'vote_features']:
+        np.testing.assert_allclose(ep[k][:, ::8, ::4].detach().cpu().numpy(), z[f'{tag}_{k}_sub'], err_msg=k, **TOL)
+    if 'pi' in ep:
+        for k, v in ep['pi'].items():
+            np.testing.assert_allclose(v.detach().cpu().numpy(), z[f'{tag}_pi_{k}'], err_msg=k, **TOL)
+
+
+def test_state_dict_layout():
+    net, _ = build('train', 64)
+    sd = net.state_dict()
+    assert len(sd) == 219
+    assert sum(p.numel() for p in net.parameters()) == 2043833
+    assert len(list(net.parameters())) == 131
+    assert sd['detection.gmm_heading.mdn.mu'].dtype == torch.float64
+    assert sd['backbone.A'].shape == (11, 53, 53)
+    for k in ['backbone.st_gcn_networks.0.gcn.conv.weight', 'backbone.st_gcn_networks.5.tcn.2.weight',
+              'backbone.conv_joint.weight', 'centervoting.conv_input.2.conv.bias',
+              'detection.vote_aggregation.mlp_module.2.weight', 'detection.gmm_size.mdn.pi.conv.weight',
+              'detection.conv_sem_obj.2.conv.bias', 'backbone.pos_embed.1.batchnorm.running_var']:
+        assert k in sd, k
+    assert sd['backbone.st_gcn_networks.0.gcn.conv.weight'].shape == (704, 64, 1, 1)
+    assert sd['backbone.conv_joint.weight'].shape == (256, 3392, 1)
+
+
+@pytest.mark.parametrize("tag,B,T", [('g3u', 1, 768), ('g3f', 2, 512)])
+def test_g3_eval_path(tag, B, T):
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(G)
+    net, cfg = build('test', T, remove_far_box=False)
+    net.eval()
+    assert abs(cases.state_checksum(net) - float(z[f'{tag}_wsum'][0])) < 1e-6 * float(z[f'{tag}_wsum'][0])
+    data = make_batch(B, T, seed=100 + T)
+    with torch.no_grad(), cpu_ops():
+        ep = net.generate_end_points(data)
+    check_endpoints(z, tag, ep)
+
+
+def run_g4(net, cfg, data, z, device, ops_ctx):
+    """Shared by the CPU and GPU twins: (1) end-to-end forward up to the votes with the
+    conditioning-aware tolerance, (2) detection head + loss + backward + AdamW step from
+    the recorded seam tensors, against the reference's numbers."""
+    from pose2room_amd.p2rnet.training import load_optimizer
+    net.train()
+    opt = load_optimizer(cfg.config, net)
+    opt.zero_grad()
+    with ops_ctx():
+        # (1) backbone + voting, end to end.  Train-mode BatchNorm divides by small batch
+        # deviations and amplifies fp32 rounding (measured ~x100 per early block), hence 5e-3.
+        xyz, feats, ep = net._votes(data)
+        assert np.array_equal(ep['seed_inds'].cpu().numpy(), z['g4_seed_inds'])
+        np.testing.assert_allclose(xyz.detach().cpu().numpy(), z['g4_vote_xyz_full'], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(feats.detach().cpu().numpy(), z['g4_vote_features_full'], rtol=5e-3, atol=5e-3)
+        # (2) head + loss from the reference's seam tensors
+        vx = torch.from_numpy(z['g4_vote_xyz_full']).to(device).requires_grad_(True)
+        vf = torch.from_numpy(z['g4_vote_features_full']).to(device).requires_grad_(True)
+        ep2 = {'seed_inds': ep['seed_inds'], 'seed_skeleton': ep['seed_skeleton'].detach(),
+               'seed_features': ep['seed_features'].detach(), 'vote_xyz': vx, 'vote_features': vf}
+        eps = {}
+        g = torch.Generator().manual_seed(123)   # the CPU stream the reference drew its noise from
+        for head, dt, D in (('center', torch.float32, 3), ('size', torch.float32, 3), ('heading', torch.float64, 2)):
+            eps[head] = torch.empty(vx.shape[0] * 128, 100, 1, D, dtype=dt).normal_(generator=g).to(device)
+        ep2, _ = net.detection(vx, vf, ep2, False, eps=eps)
+        loss = net.loss(ep2, data)
+        loss['total'].backward()
+    assert np.array_equal(ep2['aggregated_vote_inds'].cpu().numpy(), z['g4_aggregated_vote_inds'])
+    for k in ['aggregated_vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores']:
+        got = ep2[k].detach().cpu().numpy()
+        assert got.dtype == z[f'g4_{k}'].dtype, (k, got.dtype)
+        np.testing.assert_allclose(got, z[f'g4_{k}'], err_msg=k, **TOL)
+    for k, v in loss.items():
+        assert str(v.dtype) == str(z[f'g4_lossdtype_{k}']), (k, v.dtype)
+        np.testing.assert_allclose(v.item(), float(z[f'g4_loss_{k}']), rtol=1e-4, atol=1e-5, err_msg=k)
+    for k, t in (('vote_xyz', vx), ('vote_features', vf)):
+        ref_abs = float(z[f'g4_dvote_{k}_sum'][1])
+        np.testing.assert_allclose(t.grad.flatten()[:256].cpu().numpy(), z[f'g4_dvote_{k}_head'], rtol=1e-3,
+                                   atol=1e-3 * ref_abs / t.numel() + 1e-9, err_msg=k)
+        assert abs(t.grad.double().abs().sum().item() - ref_abs) <= 1e-3 * ref_abs
+    params = dict(net.named_parameters())
+    names = sorted({k[len('g4_grad_'):-len('_head')] for k in z.files if k.startswith('g4_grad_') and k.endswith('_head')})
+    det = [n for n in names if n.startswith('detection.')]
+    assert len(det) == 6
+    # gradients here reach 1e3 and some (a bias in front of a train-mode BatchNorm) are
+    # analytically zero, i.e. pure cancellation noise: tolerances are relative to the
+    # gradient scale of the head, not to each tensor's own magnitude.
+    gscale = max(float(np.abs(z[f'g4_grad_{n}_head']).max()) for n in det)
+    for name in det:
+        gr = params[name].grad
+        ref_abs = float(z[f'g4_grad_{name}_sum'][1])
+        np.testing.assert_allclose(gr.flatten()[:64].cpu().numpy(), z[f'g4_grad_{name}_head'], rtol=1e-3,
+                                   atol=2e-5 * gscale, err_msg=name)
+        assert abs(gr.double().abs().sum().item() - ref_abs) <= 1e-3 * ref_abs + 2e-5 * gscale * gr.numel(), name
+    opt.step()   # AdamW's first step is ~lr*sign(grad): only weights with a well-defined sign are compared
+    for name in det:
+        ref_g = z[f'g4_grad_{name}_head']
+        solid = np.abs(ref_g) > 1e-3 * gscale
+        got = params[name].detach().flatten()[:64].cpu().numpy()
+        np.testing.assert_allclose(got[solid], z[f'g4_post_{name}_head'][solid], rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+def test_g4_train_step():
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(G)
+    net, cfg = build('train', 256)
+    run_g4(net, cfg, make_batch(2, 256, seed=356), z, torch.device('cpu'), cpu_ops)
+
+
+def test_g4_backbone_train_mode_statistics():
+    """Train-mode forward of the whole net on CPU: BatchNorm running statistics after one
+    forward match the reference's (robust to the downstream discrete flips)."""
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(G)
+    net, cfg = build('train', 256)
+    net.train()
+    with cpu_ops():
+        net(make_batch(2, 256, seed=356))
+    np.testing.assert_allclose(net.state_dict()['backbone.st_gcn_networks.2.tcn.0.running_mean'].numpy(),
+                               z['g4_bn_running_mean'], rtol=1e-3, atol=1e-4)
