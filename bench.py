@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""P2RNet train-step benchmark on MI355X (contract in the task brief).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full train step of P2RNet on one batch of synthetic pose sequences
+already resident in HBM: zero_grad -> forward (ST-GCN backbone, centre voting, vote
+aggregation on the HIP pointnet2 ops, proposal heads) -> loss (HIP nn_distance) ->
+backward (+ RCCL gradient all-reduce for N>1) -> AdamW step -> the 10-scalar
+reduce_dict / .item() of the reference's train_step (models/training.py:25-43).
+Workload = BASELINE.json configs[2]: bs=32 per GPU, T=1024, J=53 (weak scaling).
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     -- the step against the fp32 MFMA roof (algorithmic FLOPs of the
+                  reference step / measured step time) and, per HIP kernel, the
+                  event-timed duration at the P2RNet shapes;
+  cpu_baseline -- the same host model on the host cores with the CPU oracle behind
+                  the ops ("port"), on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic fwd+bwd GFLOP per sample of the reference step (FlopCounterMode on the
+# imported reference); linear in T.
+_GFLOP_PER_SAMPLE = {512: 99.44, 768: 147.94, 1024: 196.44, 2048: 390.45}
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+
+
+def gflop_per_sample(T):
+    if T in _GFLOP_PER_SAMPLE:
+        return _GFLOP_PER_SAMPLE[T]
+    return 196.44 * T / 1024.0
+
+
+def build_trainer(device, frames, world):
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.training import Trainer, ModuleWrapper, load_optimizer
+    cfg = P2RConfig(default_config('train', data={'num_frames': frames}), device=device)
+    torch.manual_seed(42)   # p2rnet_train.yaml: seed 42, identical weights on every rank
+    net = METHODS.get('P2RNet')(cfg).to(device)
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        # one ~8.2 MB gradient payload: a single bucket, one all-reduce per step over xGMI
+        net = DDP(net, device_ids=[device.index], bucket_cap_mb=16, gradient_as_bucket_view=True)
+    else:
+        net = ModuleWrapper(net)
+    return Trainer(cfg, net, load_optimizer(cfg.config, net), device), cfg
+
+
+def kernel_microbench(device):
+    """Event-timed durations of the HIP kernels at the P2RNet shapes (B=32, N=512,
+    npoint=128, nsample=16, C=256), on the stream they are launched on."""
+    from pose2room_amd.pointnet2_ops import _ext
+    from pose2room_amd.net_utils.nn_distance import nn_distance
+    B, N, P, S, C = 32, 512, 128, 16, 256
+    g = torch.Generator().manual_seed(0)
+    xyz = (torch.randn(B, N, 3, generator=g) * 0.5).to(device)
+    feats = torch.randn(B, C, N, generator=g).to(device)
+    inds = _ext.furthest_point_sampling(xyz, P)
+    new_xyz = _ext.gather_points(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    idx = _ext.ball_query(new_xyz, xyz, 0.3, S)
+    grouped = _ext.group_points(feats, idx)
+    pc1 = torch.randn(B * 512, 3, 3, generator=g).to(device)
+    pc2 = torch.randn(B * 512, 53, 3, generator=g).to(device)
+    ops = {
+        'furthest_point_sampling': (lambda: _ext.furthest_point_sampling(xyz, P), None),
+        'ball_query': (lambda: _ext.ball_query(new_xyz, xyz, 0.3, S), None),
+        'group_points_c256': (lambda: _ext.group_points(feats, idx), 4.0 * B * C * P * S * 2 + 4.0 * B * P * S),
+        'group_points_grad_c256': (lambda: _ext.group_points_grad(grouped, idx, N), 4.0 * B * C * (P * S + N)),
+        'nn_distance_vote': (lambda: nn_distance(pc1, pc2), None),
+    }
+    out = {}
+    stream = torch.cuda.current_stream(device)
+    for name, (fn, bytes_) in ops.items():
+        for _ in range(5):
+            fn()
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[name] = {'us': round(us, 2)}
+        if bytes_:
+            out[name]['GBps'] = round(bytes_ / us / 1e3, 1)
+    return out
+
+
+def cpu_baseline(frames, budget_s=25.0):
+    """The same host model on the host cores, CPU oracle behind the ops ("port")."""
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    cores = torch.get_num_threads()
+    dev = torch.device('cpu')
+    trainer, _ = build_trainer_cpu(frames)
+    B = 2
+    batch = make_batch(B, frames, seed=1234)
+    with cpu_ops():
+        t0 = time.time()
+        trainer.train_step(dict(batch))          # warm-up (allocator, oneDNN primitives)
+        warm = time.time() - t0
+        n, t0 = 0, time.time()
+        while n < 1 or (time.time() - t0 + warm) < budget_s and n < 8:
+            trainer.train_step(dict(batch))
+            n += 1
+        dt = (time.time() - t0) / n
+    return {'value': round(B / dt, 4), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} train steps of bs={B}, T={frames}, J=53 after 1 warm-up (host model + CPU oracle ops)'}
+
+
+def build_trainer_cpu(frames):
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.training import Trainer, ModuleWrapper, load_optimizer
+    cfg = P2RConfig(default_config('train', data={'num_frames': frames}), device='cpu')
+    torch.manual_seed(42)
+    net = ModuleWrapper(METHODS.get('P2RNet')(cfg))
+    return Trainer(cfg, net, load_optimizer(cfg.config, net), torch.device('cpu')), cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE: 32)')
+    ap.add_argument('--frames', type=int, default=1024, help='T (BASELINE: 1024)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-microbench', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    trainer, cfg = build_trainer(device, args.frames, world)
+    batch = make_batch(args.batch, args.frames, seed=1234, rank=rank, device=device)   # resident in HBM
+
+    def step():
+        return trainer.train_step(dict(batch))
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        sps = world * args.batch * args.steps / elapsed
+        tflops = sps * gflop_per_sample(args.frames) / 1e3
+        line = {
+            'metric': 'P2RNet train-step samples/sec (T=1024,J=53,bs=32)', 'value': round(sps, 3),
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'P2RNet full train step, bs={args.batch}/GPU, T={args.frames}, J=53, '
+                                   f'seeds=512, proposals=128 (BASELINE configs[2])',
+                       'global_batch': world * args.batch, 'frames': args.frames,
+                       'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
+            'roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS * world,
+                         'unit': 'TFLOP/s', 'frac': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                         'traffic': None,
+                         'scope': 'whole train step: algorithmic fwd+bwd FLOPs of the reference step '
+                                  f'({gflop_per_sample(args.frames)} GFLOP/sample) / step time'},
+        }
+        if not args.no_microbench:
+            line['roofline']['kernels'] = kernel_microbench(device)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.frames)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -142,6 +142,39 @@ int p2r_nms3d(int B, int K, int stride, const double *boxes,
               const uint8_t *valid, double overlap_threshold, int old_type,
               int same_cls, uint8_t *keep, int *pick, int *npick, void *stream);
 
+/* ---- ST-GCN spatial graph convolution (models/p2rnet/modules/stgcn_layers.py) --- */
+
+/* replaces ConvTemporalGraphical.forward (stgcn_layers.py:57-67): Conv2d 1x1
+ * (64 -> K*64) followed by einsum('nkctv,kvw->nctw') with A*importance, fused;
+ * the (N,K*64,T,V) intermediate never exists.  x (N,64,T,V) f32 -> z (N,64,T,V).
+ * W [K][64][64] = the conv weight (row = output channel of plane k); the
+ * adjacency is passed in sparse column-list form: nbr u8 / coef f32 tables
+ * [sum_k Lk][V] (j-th source joint of column w in plane k and its A*importance
+ * value, zero-padded), Lk_host[K] on the HOST; bias_cv [64][V] = the conv bias
+ * pushed through the graph product, or NULL.  Called with transposed planes and
+ * row lists it yields the data gradient.  K <= 16, Lk <= 12, V <= 128. */
+int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
+                          const float *x, const float *W, const uint8_t *nbr,
+                          const float *coef, const float *bias_cv, float *z,
+                          void *stream);
+
+/* weight gradient of the above (autograd of stgcn_layers.py:62-65):
+ * dw_partial [n_blocks][K][64][64], to be summed over the leading axis by the
+ * caller (deterministic).  K must be 11, V <= 64. */
+int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host,
+                              const float *x, const float *dz,
+                              const uint8_t *nbr, const float *coef,
+                              int n_blocks, float *dw_partial, void *stream);
+
+/* gradient w.r.t. the non-zero adjacency entries (reaches edge_importance,
+ * stgcn.py:134): Wt [K][64][64] = transposed planes, nbr = the column lists;
+ * dcoef_partial [n_blocks][sum_k Lk][V], summed over the leading axis by the
+ * caller. */
+int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
+                            const float *x, const float *dz, const float *Wt,
+                            const uint8_t *nbr, int n_blocks,
+                            float *dcoef_partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,483 @@
+// stgcn_gcn.hip -- fused spatial graph convolution of the ST-GCN backbone, gfx950.
+//
+// Replaces ConvTemporalGraphical.forward (reference
+// models/p2rnet/modules/stgcn_layers.py:57-67):
+//     y = Conv2d_1x1(x)            (N,64,T,V) -> (N, K*64, T, V)   K = 11 partitions
+//     z = einsum('nkctv,kvw->nctw', y.view(N,K,64,T,V), A*importance)
+// which is 98.8 % of the reference step's FLOPs and, unfused, round-trips an
+// 11x-wide (N,704,T,V) tensor through HBM several times per block.
+//
+// MI355X design.  Per frame the op is  Z = sum_k W_k . (X . A_k) + bias-term with
+// X (64 x V), W_k (64 x 64) and A_k (V x V).  Two facts shape the kernel:
+//   * the K adjacency planes are 97 % zeros (971 non-zeros of 30 899 for the
+//     53-joint skeleton, max_hop 5), and `A * importance` keeps that support, so the
+//     graph product X . A_k is a short gather-FMA per element, not a GEMM;
+//   * what is left is a dense 64 x (K*64) by (K*64) x columns product: MFMA work.
+// A workgroup owns a tile of F frames of one sequence (F*V <= 384 columns), stages
+// the X tile in LDS once, and every lane builds its MFMA B-operand values
+// (X . A_k at its own column) on the fly from LDS with the per-column neighbour
+// list of plane k -- the aggregated tensor never exists in memory -- while
+// v_mfma_f32_32x32x2_f32 (exact fp32) accumulates Z over the K planes in AGPRs.
+// W_k streams from L2 straight into A-operand VGPRs.  HBM traffic is the
+// algorithmic minimum: read X once, write Z once.
+//
+// The same kernel computes the data gradient dX = sum_k W_k^T . (dZ . A_k^T) when
+// it is given the transposed weights and the row-wise neighbour lists.
+//
+// K order inside an MFMA step is permuted (lane-half h, step s  <->  channel
+// 32*h + s) so that a lane's 32 A-operand values are 128 contiguous bytes of a W
+// row and its B-operand rows advance by a constant LDS stride.
+#include "p2r_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int GC_C = 64;        // channels (in == out for every P2RNet block)
+constexpr int GC_NP = 384;      // padded tile width (columns) = 12 MFMA n-tiles of 32
+constexpr int GC_NT_PER_WAVE = 3;
+constexpr int GC_WAVES = 4;
+constexpr int GC_MAXK = 16;
+constexpr int GC_MAXL = 12;     // longest neighbour list supported per (plane, column)
+
+struct GcnParams {
+  int T, V, K, F;               // frames, joints, planes, frames per tile
+  int tiles_per_seq;
+  int Lk[GC_MAXK];              // neighbour-list length of plane k
+  int Lofs[GC_MAXK];            // row offset of plane k in the nbr / coef tables
+};
+
+// One (plane, n-tile) step: 32 MFMA k-steps, each consuming one freshly
+// aggregated B value per lane, used for both 32-row halves of the output.
+template <int L>
+__device__ __forceinline__ void agg_mfma(const float *__restrict__ xs_half, const int (&off)[GC_MAXL],
+                                         const float (&cf)[GC_MAXL], const float (&a0)[32],
+                                         const float (&a1)[32], floatx16 &acc0, floatx16 &acc1) {
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    float b = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) b = fmaf(cf[j], xs_half[s * GC_NP + off[j]], b);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b, acc1, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(GC_WAVES * 64, 1) void gcn_fused_kernel(
+    GcnParams p, const float *__restrict__ x, const float *__restrict__ W,
+    const uint8_t *__restrict__ nbr, const float *__restrict__ coef,
+    const float *__restrict__ bias_cv, float *__restrict__ z) {
+  extern __shared__ float xs[];  // [GC_C][GC_NP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int seq = blockIdx.x / p.tiles_per_seq;
+  const int tile = blockIdx.x % p.tiles_per_seq;
+  const int t0 = tile * p.F;
+  const int frames = min(p.F, p.T - t0);
+  const int ncols = frames * p.V;
+  const size_t row_stride = (size_t)p.T * p.V;
+  const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+  float *zg = z + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+
+  // ---- stage the X tile: 64 rows of `ncols` contiguous floats each --------------
+  for (int c = wave; c < GC_C; c += GC_WAVES) {
+    const float *src = xg + (size_t)c * row_stride;
+    for (int q = lane; q < GC_NP; q += 64) xs[c * GC_NP + q] = q < ncols ? src[q] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- this lane's three output columns ---------------------------------------
+  int colv[GC_NT_PER_WAVE], fbase[GC_NT_PER_WAVE], wj[GC_NT_PER_WAVE];
+  bool valid[GC_NT_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
+    const int col = (wave * GC_NT_PER_WAVE + i) * 32 + l31;
+    colv[i] = col;
+    valid[i] = col < ncols;
+    const int f = valid[i] ? col / p.V : 0;
+    wj[i] = valid[i] ? col - f * p.V : 0;
+    fbase[i] = f * p.V;
+  }
+
+  floatx16 acc[2][GC_NT_PER_WAVE];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int i = 0; i < GC_NT_PER_WAVE; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+
+  const float *xs_half = xs + hi * 32 * GC_NP;  // this half-wave's 32 input channels
+
+  for (int k = 0; k < p.K; ++k) {
+    // A operands: rows l31 (+32) of W_k, input channels [32*hi, 32*hi+32)
+    float a0[32], a1[32];
+    {
+      const float4 *w0 = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + l31) * GC_C + hi * 32);
+      const float4 *w1 = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + 32 + l31) * GC_C + hi * 32);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 u = w0[q], v = w1[q];
+        a0[4 * q + 0] = u.x; a0[4 * q + 1] = u.y; a0[4 * q + 2] = u.z; a0[4 * q + 3] = u.w;
+        a1[4 * q + 0] = v.x; a1[4 * q + 1] = v.y; a1[4 * q + 2] = v.z; a1[4 * q + 3] = v.w;
+      }
+    }
+    const int L = p.Lk[k];
+    const int lofs = p.Lofs[k];
+#pragma unroll
+    for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
+      int off[GC_MAXL];
+      float cf[GC_MAXL];
+#pragma unroll
+      for (int j = 0; j < GC_MAXL; ++j) {
+        const bool on = j < L;
+        const int row = (on ? lofs + j : lofs) * p.V + wj[i];
+        off[j] = fbase[i] + (int)nbr[row];
+        cf[j] = (on && valid[i]) ? coef[row] : 0.f;
+      }
+      switch (L) {
+        case 1: agg_mfma<1>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 2: agg_mfma<2>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 3: agg_mfma<3>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 4: agg_mfma<4>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 5: agg_mfma<5>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 6: agg_mfma<6>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 7:
+        case 8: agg_mfma<8>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 9:
+        case 10: agg_mfma<10>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        default: agg_mfma<12>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+      }
+    }
+  }
+
+  // ---- epilogue: D[row][col], row = (r&3) + 8*(r>>2) + 4*hi (+32 for the 2nd half)
+#pragma unroll
+  for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
+    if (!valid[i]) continue;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = acc[m][i][r];
+        if (bias_cv) v += bias_cv[row * p.V + wj[i]];
+        zg[(size_t)row * row_stride + colv[i]] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// x (N,64,T,V) -> z (N,64,T,V).  W [K][64][64] (row = output channel); nbr u8 /
+// coef f32 tables [sum_k L_k][V] (column-wise neighbour lists of plane k, padded
+// with coef 0); Lk[K] on the host; bias_cv [64][V] or NULL.
+extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host, const float *x,
+                                     const float *W, const uint8_t *nbr, const float *coef,
+                                     const float *bias_cv, float *z, void *stream) {
+  if (N < 0 || T <= 0 || V <= 0 || V > 128 || K <= 0 || K > GC_MAXK) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  GcnParams p;
+  p.T = T; p.V = V; p.K = K;
+  p.F = GC_NP / V;
+  if (p.F < 1) return P2R_EINVAL;
+  if (p.F > T) p.F = T;
+  p.tiles_per_seq = p2r_cdiv(T, p.F);
+  int ofs = 0;
+  for (int k = 0; k < K; ++k) {
+    if (Lk_host[k] < 1 || Lk_host[k] > GC_MAXL) return P2R_EINVAL;
+    p.Lk[k] = Lk_host[k];
+    p.Lofs[k] = ofs;
+    ofs += Lk_host[k];
+  }
+  const long long blocks = (long long)N * p.tiles_per_seq;
+  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+  const size_t lds = (size_t)GC_C * GC_NP * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)gcn_fused_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gcn_fused_kernel, dim3((unsigned)blocks), dim3(GC_WAVES * 64), lds,
+                     p2r_stream(stream), p, x, W, nbr, coef, bias_cv, z);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// =============================================================================
+// Weight gradient:  dW_k[c][ci] = sum over (n, t, w) of dZ[c, t, w] * (X . A_k)[ci, t, w]
+// (reference: autograd through stgcn_layers.py:62-65).
+//
+// GEMM view per plane k: M = 64 (c), N = 64 (ci), reduction over every column of
+// the batch.  A persistent grid of workgroups walks the (sequence, 4-frame) tiles;
+// dZ and X tiles are staged in LDS (row length odd: conflict-free column reads);
+// reduction steps are ordered (joint w major, frame minor) so the 4 columns of one
+// v_mfma_f32_16x16x4_f32 step are the 4 frames of ONE joint: the neighbour list of
+// (k, w) is then wave-uniform (scalar loads), every (ci, column) aggregate is built
+// exactly once, and it feeds the 4 output-row tiles.  Each wave keeps its
+// 44 accumulator tiles (11 planes x 64 rows x 16 ci columns) in AGPRs across all its
+// tiles and writes one partial per workgroup; partials are summed deterministically
+// by the caller.
+// =============================================================================
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int DW_F = 4;
+constexpr int DW_MAXV = 64;
+constexpr int DW_MAXK = 11;   // accumulator tiles are statically allocated for this many planes
+
+template <int KP>
+__global__ __launch_bounds__(256, 1) void gcn_dw_kernel(GcnParams p, int n_seq, int row_len,
+                                                        const float *__restrict__ x,
+                                                        const float *__restrict__ dz,
+                                                        const uint8_t *__restrict__ nbr,
+                                                        const float *__restrict__ coef,
+                                                        float *__restrict__ dw_partial) {
+  extern __shared__ float lds[];
+  float *dzs = lds;                         // [64][row_len]
+  float *xs = lds + GC_C * row_len;         // [64][row_len]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;                  // frame within the tile / MFMA k index
+  const int r = lane & 15;
+
+  const int tiles_per_seq = (p.T + DW_F - 1) / DW_F;
+  const int total_tiles = n_seq * tiles_per_seq;
+  const size_t row_stride = (size_t)p.T * p.V;
+
+  floatx4 acc[KP][4];
+#pragma unroll
+  for (int k = 0; k < KP; ++k)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[k][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int seq = tile / tiles_per_seq;
+    const int t0 = (tile % tiles_per_seq) * DW_F;
+    const int ncols = min(DW_F, p.T - t0) * p.V;
+    const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    __syncthreads();  // previous tile fully consumed
+    for (int c = wave; c < GC_C; c += 4) {
+      const float *sx = xg + (size_t)c * row_stride;
+      const float *sd = dg + (size_t)c * row_stride;
+      for (int q = lane; q < DW_F * p.V; q += 64) {
+        const bool in = q < ncols;
+        xs[c * row_len + q] = in ? sx[q] : 0.f;
+        dzs[c * row_len + q] = in ? sd[q] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    const float *xrow = xs + (16 * wave + r) * row_len + g * p.V;   // this lane's ci row, frame g
+    const float *drow = dzs + r * row_len + g * p.V;                 // + 16*m rows
+    for (int w = 0; w < p.V; ++w) {
+      float a[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = drow[16 * m * row_len + w];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int L = p.Lk[k];
+        const int base = p.Lofs[k] * p.V + w;
+        float b = 0.f;
+        for (int j = 0; j < L; ++j) b = fmaf(coef[base + j * p.V], xrow[nbr[base + j * p.V]], b);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[k][m], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial[block][k][c][ci]: D[row = 4*g + reg][col = r] -> c = 16*m + row, ci = 16*wave + r
+  float *out = dw_partial + (size_t)blockIdx.x * KP * GC_C * GC_C;
+#pragma unroll
+  for (int k = 0; k < KP; ++k)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        out[((size_t)k * GC_C + 16 * m + 4 * g + q) * GC_C + 16 * wave + r] = acc[k][m][q];
+}
+
+// =============================================================================
+// Adjacency gradient at the non-zero entries:
+//   dcoef[k][j][w] = sum over (n, t, ci) of X[ci, t, v_j(k,w)] * (W_k^T dZ)[ci, t, w]
+// (the gradient reaching `A * importance`, stgcn.py:134, needed for edge_importance).
+// Dense part H_k = W_k^T . dZ on MFMA exactly like the forward kernel, but per plane
+// (no accumulation over k); the dZ B-operands are loaded once per tile into VGPRs
+// and reused by all planes, the X tile sits in LDS for the gathers, and the per-lane
+// partial products are reduced with LDS float atomics into a [sum L_k][V] table that
+// each persistent workgroup writes out once.
+// =============================================================================
+constexpr int DC_NT = 6;  // n-tiles per wave (two waves share the same columns, one per row half)
+
+__global__ __launch_bounds__(256, 1) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
+                                                           const float *__restrict__ x,
+                                                           const float *__restrict__ dz,
+                                                           const float *__restrict__ Wt,
+                                                           const uint8_t *__restrict__ nbr,
+                                                           float *__restrict__ dcoef_partial) {
+  extern __shared__ float lds[];
+  float *xs = lds;                          // [64][GC_NP]
+  float *dcs = lds + GC_C * GC_NP;          // [ltot][V]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int mt = wave & 1;                  // row half (ci) of H owned by this wave
+  const int ntb = (wave >> 1) * DC_NT;      // first n-tile
+
+  for (int q = tid; q < ltot * p.V; q += 256) dcs[q] = 0.f;
+
+  const int total_tiles = n_seq * p.tiles_per_seq;
+  const size_t row_stride = (size_t)p.T * p.V;
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int seq = tile / p.tiles_per_seq;
+    const int t0 = (tile % p.tiles_per_seq) * p.F;
+    const int ncols = min(p.F, p.T - t0) * p.V;
+    const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    __syncthreads();
+    for (int c = wave; c < GC_C; c += 4) {
+      const float *src = xg + (size_t)c * row_stride;
+      for (int q = lane; q < GC_NP; q += 64) xs[c * GC_NP + q] = q < ncols ? src[q] : 0.f;
+    }
+
+    int colv[DC_NT], fbase[DC_NT], wj[DC_NT];
+    bool valid[DC_NT];
+    float bz[DC_NT][32];                    // dZ[c = 32*hi + s][col]: B operands, reused by every plane
+#pragma unroll
+    for (int i = 0; i < DC_NT; ++i) {
+      const int col = (ntb + i) * 32 + l31;
+      colv[i] = col;
+      valid[i] = col < ncols;
+      const int f = valid[i] ? col / p.V : 0;
+      wj[i] = valid[i] ? col - f * p.V : 0;
+      fbase[i] = f * p.V;
+#pragma unroll
+      for (int s = 0; s < 32; ++s)
+        bz[i][s] = valid[i] ? dg[(size_t)(32 * hi + s) * row_stride + col] : 0.f;
+    }
+    __syncthreads();
+
+    for (int k = 0; k < p.K; ++k) {
+      float a[32];                           // Wt[k][ci = 32*mt + l31][c = 32*hi .. +32)
+      const float4 *w0 = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 32 * mt + l31) * GC_C + hi * 32);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 u = w0[q];
+        a[4 * q + 0] = u.x; a[4 * q + 1] = u.y; a[4 * q + 2] = u.z; a[4 * q + 3] = u.w;
+      }
+      const int L = p.Lk[k];
+      const int lofs = p.Lofs[k];
+#pragma unroll
+      for (int i = 0; i < DC_NT; ++i) {
+        floatx16 h;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bz[i][s], h, 0, 0, 0);
+        // h[q] = H_k[ci = 32*mt + (q&3) + 8*(q>>2) + 4*hi][col_i]
+        if (valid[i]) {
+          for (int j = 0; j < L; ++j) {
+            const int trow = (lofs + j) * p.V + wj[i];
+            const float *xcol = xs + fbase[i] + (int)nbr[trow];
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int ci = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hi;
+              part = fmaf(h[q], xcol[ci * GC_NP], part);
+            }
+            atomicAdd(&dcs[trow], part);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float *out = dcoef_partial + (size_t)blockIdx.x * ltot * p.V;
+  for (int q = tid; q < ltot * p.V; q += 256) out[q] = dcs[q];
+}
+
+}  // namespace
+
+static int gcn_fill_params(GcnParams &p, int T, int V, int K, const int *Lk_host, int F) {
+  if (T <= 0 || V <= 0 || V > DW_MAXV || K <= 0 || K > GC_MAXK) return P2R_EINVAL;
+  p.T = T; p.V = V; p.K = K; p.F = F < T ? F : T;
+  if (p.F < 1) return P2R_EINVAL;
+  p.tiles_per_seq = p2r_cdiv(T, p.F);
+  int ofs = 0;
+  for (int k = 0; k < K; ++k) {
+    if (Lk_host[k] < 1 || Lk_host[k] > GC_MAXL) return P2R_EINVAL;
+    p.Lk[k] = Lk_host[k];
+    p.Lofs[k] = ofs;
+    ofs += Lk_host[k];
+  }
+  return ofs;
+}
+
+// dW partials: x, dz (N,64,T,V) -> dw_partial [n_blocks][K][64][64]; the caller sums
+// over the leading axis.  Returns the number of workgroups used through *n_blocks
+// when dw_partial is NULL (size query), else launches.  K must be 11.
+extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host, const float *x,
+                                         const float *dz, const uint8_t *nbr, const float *coef,
+                                         int n_blocks, float *dw_partial, void *stream) {
+  GcnParams p;
+  const int ltot = gcn_fill_params(p, T, V, K, Lk_host, DW_F);
+  if (ltot < 0) return ltot;
+  if (K != DW_MAXK || N < 0 || n_blocks < 1) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  const int row_len = DW_F * V + ((DW_F * V) % 2 == 0 ? 1 : 0);  // odd row length
+  const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float);
+  if (lds > 160 * 1024) return P2R_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)gcn_dw_kernel<DW_MAXK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gcn_dw_kernel<DW_MAXK>, dim3(n_blocks), dim3(256), lds, p2r_stream(stream), p, N,
+                     row_len, x, dz, nbr, coef, dw_partial);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// dcoef partials: x, dz (N,64,T,V), Wt [K][64(ci)][64(c)] (transposed planes) ->
+// dcoef_partial [n_blocks][sum L_k][V]; the caller sums over the leading axis.
+extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host, const float *x,
+                                       const float *dz, const float *Wt, const uint8_t *nbr,
+                                       int n_blocks, float *dcoef_partial, void *stream) {
+  GcnParams p;
+  const int ltot = gcn_fill_params(p, T, V, K, Lk_host, GC_NP / (V > 0 ? V : 1));
+  if (ltot < 0) return ltot;
+  if (N < 0 || n_blocks < 1) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  const size_t lds = ((size_t)GC_C * GC_NP + (size_t)ltot * V) * sizeof(float);
+  if (lds > 160 * 1024) return P2R_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)gcn_dcoef_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gcn_dcoef_kernel, dim3(n_blocks), dim3(256), lds, p2r_stream(stream), p, N, ltot, x,
+                     dz, Wt, nbr, dcoef_partial);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

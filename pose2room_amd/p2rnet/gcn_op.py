@@ -1,0 +1,118 @@
+"""Fused spatial graph convolution op (HIP kernels in csrc/stgcn_gcn.hip).
+
+`graph_conv(x, weight, bias, Aeff, tables)` computes exactly what the reference's
+ConvTemporalGraphical.forward does (stgcn_layers.py:57-67):
+    einsum('nkctv,kvw->nctw', conv1x1(x; weight, bias).view(N,K,C,T,V), Aeff)
+for C = 64, without materialising the K*C-channel tensor, and is differentiable
+w.r.t. x, weight, bias and Aeff (= A * edge_importance).
+
+Only the sparse form of Aeff is used (its zero pattern is the skeleton's, fixed);
+the bias enters as bias_cv[c,w] = sum_k b_k[c] * sum_v Aeff[k,v,w], built with torch
+ops so autograd provides db and the bias share of dAeff.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from . import gcn_tables
+
+_N_BLOCKS = 256     # persistent workgroups of the reduction kernels (one per CU)
+
+
+class GraphTables:
+    """Device-resident neighbour tables of one adjacency pattern (built once)."""
+
+    def __init__(self, A):
+        self.K, self.V = int(A.shape[0]), int(A.shape[1])
+        self.nbr_c, self.gidx_c, self.Lk_c = gcn_tables.build(A, transpose=False)
+        self.nbr_r, self.gidx_r, self.Lk_r = gcn_tables.build(A, transpose=True)
+        self.LkA_c = (ctypes.c_int * self.K)(*self.Lk_c)
+        self.LkA_r = (ctypes.c_int * self.K)(*self.Lk_r)
+        self._dev = {}
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = dict(nbr_c=self.nbr_c.to(device), gidx_c=self.gidx_c.to(device),
+                                  nbr_r=self.nbr_r.to(device), gidx_r=self.gidx_r.to(device))
+        return self._dev[key]
+
+
+def _gcn_forward(x, W, nbr, coef, LkA, bias_cv, tables):
+    N, C, T, V = x.shape
+    z = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().p2r_stgcn_gcn_forward(
+            N, T, V, tables.K, LkA, _lib.ptr(x), _lib.ptr(W), _lib.ptr(nbr), _lib.ptr(coef),
+            _lib.ptr(bias_cv), _lib.ptr(z), _lib.current_stream(x.device)), "stgcn_gcn_forward")
+    return z
+
+
+class _GraphConv(Function):
+    @staticmethod
+    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables):
+        # weight (K*64, 64): plane k rows = output channels of plane k
+        dev = x.device
+        t = tables.on(dev)
+        x = x.contiguous()
+        W = weight.contiguous()
+        z = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables)
+        ctx.save_for_backward(x, W, coef_c, coef_r)
+        ctx.tables = tables
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, W, coef_c, coef_r = ctx.saved_tensors
+        tables = ctx.tables
+        dev = x.device
+        t = tables.on(dev)
+        dz = dz.contiguous()
+        N, C, T, V = x.shape
+        K = tables.K
+        Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
+        dx = dW = dcoef = dbias = None
+        if ctx.needs_input_grad[0]:
+            # dX = sum_k W_k^T (dZ . A_k^T): same kernel, transposed planes + row lists
+            dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
+        lib = _lib.lib()
+        st = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[1]:
+                part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
+                _lib.check(lib.p2r_stgcn_gcn_weight_grad(
+                    N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(t['nbr_c']),
+                    _lib.ptr(coef_c.contiguous()), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_weight_grad")
+                dW = part.sum(0).view(K * C, C)
+            if ctx.needs_input_grad[2]:
+                ltot = coef_c.shape[0]
+                part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
+                _lib.check(lib.p2r_stgcn_gcn_coef_grad(
+                    N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wt), _lib.ptr(t['nbr_c']),
+                    _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
+                dcoef = part.sum(0)
+        if ctx.needs_input_grad[4]:
+            dbias = dz.sum(dim=(0, 2))                                 # (C, V)
+        return dx, dW, dcoef, None, dbias, None
+
+
+def supported(x, weight, A):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64
+            and weight.shape[1] == 64 and weight.shape[0] == 64 * A.shape[0] and A.shape[0] == 11
+            and A.shape[1] <= 64)
+
+
+def graph_conv(x, weight, bias, Aeff, tables):
+    """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V)."""
+    K, V = tables.K, tables.V
+    t = tables.on(x.device)
+    w2 = weight.reshape(K * 64, 64)
+    coef_c = gcn_tables.coefficients(Aeff, t['gidx_c'])
+    coef_r = gcn_tables.coefficients(Aeff.detach(), t['gidx_r'])      # only used for dX
+    if bias is not None:
+        bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
+    else:
+        bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
+    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables)

@@ -38,6 +38,10 @@ class STGCN(nn.Module):
         self.st_gcn_networks = nn.ModuleList(
             [st_gcn_block(width, 64, kernel_size, 1, residual=False)] +
             [st_gcn_block(64, 64, kernel_size, 1) for _ in range(5)])
+        from ..gcn_op import GraphTables
+        tables = GraphTables(self.graph.A)     # sparse form of the skeleton adjacency for the fused kernels
+        for blk in self.st_gcn_networks:
+            blk.gcn.tables = tables
         self.conv_joint = nn.Conv1d(cfg.dataset_config.joint_num * 64, out_channels, kernel_size=1)
         self.edge_importance = nn.ParameterList(
             [nn.Parameter(torch.ones(self.A.size())) for _ in self.st_gcn_networks])

@@ -105,12 +105,18 @@ class ConvTemporalGraphical(nn.Module):
         super().__init__()
         self.kernel_size = kernel_size
         self.out_channels = out_channels
+        self.tables = None      # GraphTables of the adjacency pattern: enables the fused HIP path
+        self.fused = True
         self.conv = nn.Conv2d(in_channels, out_channels * kernel_size, kernel_size=(t_kernel_size, 1),
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
     def forward(self, x, A):
         assert A.size(0) == self.kernel_size
+        if self.tables is not None and self.fused:
+            from .. import gcn_op
+            if gcn_op.supported(x, self.conv.weight, A):
+                return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables), A
         y = self.conv(x)
         n, kc, t, v = y.size()
         y = y.view(n, self.kernel_size, kc // self.kernel_size, t, v)

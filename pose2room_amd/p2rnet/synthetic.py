@@ -33,7 +33,15 @@ def make_batch(batch_size, num_frames, seed=1234, rank=0, device=None):
     steps[:, 1:, 2] = torch.randn(B, T - 1, generator=g) * 0.05
     hip = torch.cumsum(steps, 1).clamp_(-3.0, 3.0)
     hip[..., 1] = 0.9
-    joints = hip[:, :, None, :] + skeleton_template()[None, None] + \
+    # articulated motion: every joint swings around its template offset with its own
+    # frequency / phase / direction (0.15 m amplitude), plus 2 cm sensor jitter
+    tt = torch.arange(T, dtype=torch.float32)[None, :, None]
+    freq = torch.rand(B, 1, N_JOINTS, generator=g) * 0.25 + 0.05
+    phase = torch.rand(B, 1, N_JOINTS, generator=g) * (2 * math.pi)
+    axis = torch.randn(B, 1, N_JOINTS, 3, generator=g)
+    axis = axis / axis.norm(dim=-1, keepdim=True)
+    swing = 0.15 * torch.sin(freq * tt + phase)[..., None] * axis
+    joints = hip[:, :, None, :] + skeleton_template()[None, None] + swing + \
         torch.randn(B, T, N_JOINTS, 3, generator=g) * 0.02
     joints[:, :, 0] = hip
 

@@ -80,11 +80,11 @@ def run_g4(net, cfg, data, z, device, ops_ctx):
     opt.zero_grad()
     with ops_ctx():
         # (1) backbone + voting, end to end.  Train-mode BatchNorm divides by small batch
-        # deviations and amplifies fp32 rounding (measured ~x100 per early block), hence 5e-3.
+        # deviations and amplifies fp32 rounding differences (measured x26 over the six blocks with the hash fill), hence 1e-3.
         xyz, feats, ep = net._votes(data)
         assert np.array_equal(ep['seed_inds'].cpu().numpy(), z['g4_seed_inds'])
-        np.testing.assert_allclose(xyz.detach().cpu().numpy(), z['g4_vote_xyz_full'], rtol=5e-3, atol=5e-3)
-        np.testing.assert_allclose(feats.detach().cpu().numpy(), z['g4_vote_features_full'], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(xyz.detach().cpu().numpy(), z['g4_vote_xyz_full'], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(feats.detach().cpu().numpy(), z['g4_vote_features_full'], rtol=1e-3, atol=1e-3)
         # (2) head + loss from the reference's seam tensors
         vx = torch.from_numpy(z['g4_vote_xyz_full']).to(device).requires_grad_(True)
         vf = torch.from_numpy(z['g4_vote_features_full']).to(device).requires_grad_(True)
@@ -121,9 +121,9 @@ def run_g4(net, cfg, data, z, device, ops_ctx):
     for name in det:
         gr = params[name].grad
         ref_abs = float(z[f'g4_grad_{name}_sum'][1])
-        np.testing.assert_allclose(gr.flatten()[:64].cpu().numpy(), z[f'g4_grad_{name}_head'], rtol=1e-3,
-                                   atol=2e-5 * gscale, err_msg=name)
-        assert abs(gr.double().abs().sum().item() - ref_abs) <= 1e-3 * ref_abs + 2e-5 * gscale * gr.numel(), name
+        np.testing.assert_allclose(gr.flatten()[:64].cpu().numpy(), z[f'g4_grad_{name}_head'], rtol=2e-3,
+                                   atol=5e-4 * gscale, err_msg=name)
+        assert abs(gr.double().abs().sum().item() - ref_abs) <= 2e-3 * ref_abs + 5e-4 * gscale * gr.numel(), name
     opt.step()   # AdamW's first step is ~lr*sign(grad): only weights with a well-defined sign are compared
     for name in det:
         ref_g = z[f'g4_grad_{name}_head']
