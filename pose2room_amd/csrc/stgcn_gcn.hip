@@ -47,33 +47,71 @@ struct GcnParams {
   int Lofs[GC_MAXK];            // row offset of plane k in the nbr / coef tables
 };
 
-// One (plane, n-tile) step: 32 MFMA k-steps, each consuming one freshly
-// aggregated B value per lane, used for both 32-row halves of the output.
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GC_ROW = GC_NP + 1;   // odd LDS row stride: the two 16-lane groups of a half-wave
+                                    // (rows 16 apart) land on bank sets shifted by 16
+constexpr int GC_THREADS = 512;     // 8 waves: two per SIMD, so one wave's LDS / L2 waits hide
+                                    // under the other's MFMAs
+constexpr int GC_NT16 = 3;          // 16-column n-tiles per wave (8 waves x 3 x 16 = 384 columns)
+
+// One (plane, n-tile) unit with v_mfma_f32_16x16x4_f32: 16 k-steps; lane (g = lane>>4,
+// r = lane&15) builds B[k = g][col = r] = (X . A_k)[channel 16g + s][column] from L
+// gathered LDS values and feeds the four 16-row output tiles.  Gathers of step s+2/s+3
+// are issued before the FMAs / MFMAs of steps s/s+1.
 template <int L>
-__device__ __forceinline__ void agg_mfma(const float *__restrict__ xs_half, const int (&off)[GC_MAXL],
-                                         const float (&cf)[GC_MAXL], const float (&a0)[32],
-                                         const float (&a1)[32], floatx16 &acc0, floatx16 &acc1) {
+__device__ __forceinline__ void agg_mfma16(const float *__restrict__ xg, const int (&off)[GC_MAXL],
+                                           const float (&cf)[GC_MAXL], const float (&a)[4][16],
+                                           floatx4_t (&acc)[4]) {
+  float xc[2][L], xn[2][L];
 #pragma unroll
-  for (int s = 0; s < 32; ++s) {
-    float b = 0.f;
+  for (int j = 0; j < L; ++j) {
+    xc[0][j] = xg[off[j]];
+    xc[1][j] = xg[GC_ROW + off[j]];
+  }
 #pragma unroll
-    for (int j = 0; j < L; ++j) b = fmaf(cf[j], xs_half[s * GC_NP + off[j]], b);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b, acc1, 0, 0, 0);
+  for (int pr = 0; pr < 8; ++pr) {
+    if (pr + 1 < 8) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        xn[0][j] = xg[(2 * pr + 2) * GC_ROW + off[j]];
+        xn[1][j] = xg[(2 * pr + 3) * GC_ROW + off[j]];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      b0 = fmaf(cf[j], xc[0][j], b0);
+      b1 = fmaf(cf[j], xc[1][j], b1);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][2 * pr], b0, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][2 * pr + 1], b1, acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      xc[0][j] = xn[0][j];
+      xc[1][j] = xn[1][j];
+    }
   }
 }
 
-__global__ __launch_bounds__(GC_WAVES * 64, 1) void gcn_fused_kernel(
-    GcnParams p, const float *__restrict__ x, const float *__restrict__ W,
+__global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
+    GcnParams p, int ltot, const float *__restrict__ x, const float *__restrict__ W,
     const uint8_t *__restrict__ nbr, const float *__restrict__ coef,
     const float *__restrict__ bias_cv, float *__restrict__ z) {
-  extern __shared__ float xs[];  // [GC_C][GC_NP]
+  extern __shared__ float xs[];                       // [GC_C][GC_ROW] floats, then the int2 table
+  int2 *tbl = reinterpret_cast<int2 *>(xs + GC_C * GC_ROW);   // GC_C*GC_ROW floats = 8-byte multiple
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
+  const int g = lane >> 4;
+  const int r = lane & 15;
 
   const int seq = blockIdx.x / p.tiles_per_seq;
   const int tile = blockIdx.x % p.tiles_per_seq;
@@ -81,22 +119,27 @@ __global__ __launch_bounds__(GC_WAVES * 64, 1) void gcn_fused_kernel(
   const int frames = min(p.F, p.T - t0);
   const int ncols = frames * p.V;
   const size_t row_stride = (size_t)p.T * p.V;
-  const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+  const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
   float *zg = z + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
 
-  // ---- stage the X tile: 64 rows of `ncols` contiguous floats each --------------
-  for (int c = wave; c < GC_C; c += GC_WAVES) {
-    const float *src = xg + (size_t)c * row_stride;
-    for (int q = lane; q < GC_NP; q += 64) xs[c * GC_NP + q] = q < ncols ? src[q] : 0.f;
+  // ---- stage the X tile (64 rows of `ncols` contiguous floats) and the (nbr, coef) table
+  for (int c = wave; c < GC_C; c += GC_THREADS / 64) {
+    const float *src = xgm + (size_t)c * row_stride;
+#pragma unroll
+    for (int q0 = 0; q0 < GC_NP; q0 += 64) {
+      const int q = q0 + lane;
+      xs[c * GC_ROW + q] = q < ncols ? src[q] : 0.f;
+    }
   }
+  for (int e = tid; e < ltot * p.V; e += GC_THREADS)
+    tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
   __syncthreads();
 
-  // ---- this lane's three output columns ---------------------------------------
-  int colv[GC_NT_PER_WAVE], fbase[GC_NT_PER_WAVE], wj[GC_NT_PER_WAVE];
-  bool valid[GC_NT_PER_WAVE];
+  int colv[GC_NT16], fbase[GC_NT16], wj[GC_NT16];
+  bool valid[GC_NT16];
 #pragma unroll
-  for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
-    const int col = (wave * GC_NT_PER_WAVE + i) * 32 + l31;
+  for (int i = 0; i < GC_NT16; ++i) {
+    const int col = (wave * GC_NT16 + i) * 16 + r;
     colv[i] = col;
     valid[i] = col < ncols;
     const int f = valid[i] ? col / p.V : 0;
@@ -104,68 +147,65 @@ __global__ __launch_bounds__(GC_WAVES * 64, 1) void gcn_fused_kernel(
     fbase[i] = f * p.V;
   }
 
-  floatx16 acc[2][GC_NT_PER_WAVE];
+  floatx4_t acc[GC_NT16][4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int i = 0; i < GC_NT16; ++i)
 #pragma unroll
-    for (int i = 0; i < GC_NT_PER_WAVE; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+    for (int m = 0; m < 4; ++m) acc[i][m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-  const float *xs_half = xs + hi * 32 * GC_NP;  // this half-wave's 32 input channels
+  const float *xg = xs + g * 16 * GC_ROW;   // this lane group's 16 input channels
 
   for (int k = 0; k < p.K; ++k) {
-    // A operands: rows l31 (+32) of W_k, input channels [32*hi, 32*hi+32)
-    float a0[32], a1[32];
-    {
-      const float4 *w0 = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + l31) * GC_C + hi * 32);
-      const float4 *w1 = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + 32 + l31) * GC_C + hi * 32);
+    // A operands: W_k[row 16m + r][channels 16g .. 16g+15]
+    float a[4][16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 u = w0[q], v = w1[q];
-        a0[4 * q + 0] = u.x; a0[4 * q + 1] = u.y; a0[4 * q + 2] = u.z; a0[4 * q + 3] = u.w;
-        a1[4 * q + 0] = v.x; a1[4 * q + 1] = v.y; a1[4 * q + 2] = v.z; a1[4 * q + 3] = v.w;
+    for (int m = 0; m < 4; ++m) {
+      const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 u = wp[q];
+        a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
       }
     }
     const int L = p.Lk[k];
     const int lofs = p.Lofs[k];
 #pragma unroll
-    for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
+    for (int i = 0; i < GC_NT16; ++i) {
       int off[GC_MAXL];
       float cf[GC_MAXL];
 #pragma unroll
       for (int j = 0; j < GC_MAXL; ++j) {
         const bool on = j < L;
-        const int row = (on ? lofs + j : lofs) * p.V + wj[i];
-        off[j] = fbase[i] + (int)nbr[row];
-        cf[j] = (on && valid[i]) ? coef[row] : 0.f;
+        const int2 e = tbl[(on ? lofs + j : lofs) * p.V + wj[i]];
+        off[j] = fbase[i] + e.x;
+        cf[j] = (on && valid[i]) ? __int_as_float(e.y) : 0.f;
       }
       switch (L) {
-        case 1: agg_mfma<1>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        case 2: agg_mfma<2>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        case 3: agg_mfma<3>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        case 4: agg_mfma<4>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        case 5: agg_mfma<5>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        case 6: agg_mfma<6>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 1: agg_mfma16<1>(xg, off, cf, a, acc[i]); break;
+        case 2: agg_mfma16<2>(xg, off, cf, a, acc[i]); break;
+        case 3: agg_mfma16<3>(xg, off, cf, a, acc[i]); break;
+        case 4: agg_mfma16<4>(xg, off, cf, a, acc[i]); break;
+        case 5: agg_mfma16<5>(xg, off, cf, a, acc[i]); break;
+        case 6: agg_mfma16<6>(xg, off, cf, a, acc[i]); break;
         case 7:
-        case 8: agg_mfma<8>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 8: agg_mfma16<8>(xg, off, cf, a, acc[i]); break;
         case 9:
-        case 10: agg_mfma<10>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
-        default: agg_mfma<12>(xs_half, off, cf, a0, a1, acc[0][i], acc[1][i]); break;
+        case 10: agg_mfma16<10>(xg, off, cf, a, acc[i]); break;
+        default: agg_mfma16<12>(xg, off, cf, a, acc[i]); break;
       }
     }
   }
 
-  // ---- epilogue: D[row][col], row = (r&3) + 8*(r>>2) + 4*hi (+32 for the 2nd half)
+  // ---- epilogue: 16x16 tile D[row = 4g + q][col = r]
 #pragma unroll
-  for (int i = 0; i < GC_NT_PER_WAVE; ++i) {
+  for (int i = 0; i < GC_NT16; ++i) {
     if (!valid[i]) continue;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 4; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v = acc[m][i][r];
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * m + 4 * g + q;
+        float v = acc[i][m][q];
         if (bias_cv) v += bias_cv[row * p.V + wj[i]];
         zg[(size_t)row * row_stride + colv[i]] = v;
       }
@@ -198,16 +238,17 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
   }
   const long long blocks = (long long)N * p.tiles_per_seq;
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
-  const size_t lds = (size_t)GC_C * GC_NP * sizeof(float);
+  const size_t lds = ((size_t)GC_C * GC_ROW + 2) * sizeof(float) + (size_t)ofs * V * sizeof(int2);
+  if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)gcn_fused_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gcn_fused_kernel, dim3((unsigned)blocks), dim3(GC_WAVES * 64), lds,
-                     p2r_stream(stream), p, x, W, nbr, coef, bias_cv, z);
+  hipLaunchKernelGGL(gcn_fused_kernel, dim3((unsigned)blocks), dim3(GC_THREADS), lds,
+                     p2r_stream(stream), p, ofs, x, W, nbr, coef, bias_cv, z);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -233,34 +274,69 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int DW_F = 4;
 constexpr int DW_MAXV = 64;
-constexpr int DW_MAXK = 11;   // accumulator tiles are statically allocated for this many planes
+constexpr int DW_MAXK = 11;
+constexpr int DW_PL = 6;          // planes per wave half (two halves cover up to 12 planes)
+constexpr int DW_THREADS = 512;
 
-template <int KP>
-__global__ __launch_bounds__(256, 1) void gcn_dw_kernel(GcnParams p, int n_seq, int row_len,
-                                                        const float *__restrict__ x,
-                                                        const float *__restrict__ dz,
-                                                        const uint8_t *__restrict__ nbr,
-                                                        const float *__restrict__ coef,
-                                                        float *__restrict__ dw_partial) {
+struct DwSets {                   // host-balanced split of the planes over the two wave halves
+  int plane[2][DW_PL];            // plane id or -1
+};
+
+// b[f] += sum_j coef * X[ci row][frame f, joint nbr_j]  for one plane; L compile-time.
+template <int L>
+__device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstride,
+                                         const float *__restrict__ xrow, int V, bool live, float (&b)[DW_F]) {
+  int2 e[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) e[j] = trow[j * tstride];
+  float xv[L][DW_F];
+#pragma unroll
+  for (int j = 0; j < L; ++j)
+#pragma unroll
+    for (int f = 0; f < DW_F; ++f) xv[j][f] = xrow[f * V + e[j].x];
+#pragma unroll
+  for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const float cf = live ? __int_as_float(e[j].y) : 0.f;
+#pragma unroll
+    for (int f = 0; f < DW_F; ++f) b[f] = fmaf(cf, xv[j][f], b[f]);
+  }
+}
+
+__global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSets sets, int n_seq,
+                                                               int row_len, int ltot,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ dz,
+                                                               const uint8_t *__restrict__ nbr,
+                                                               const float *__restrict__ coef,
+                                                               float *__restrict__ dw_partial) {
   extern __shared__ float lds[];
-  float *dzs = lds;                         // [64][row_len]
-  float *xs = lds + GC_C * row_len;         // [64][row_len]
+  float *dzs = lds;                                   // [64][row_len]
+  float *xs = lds + GC_C * row_len;                   // [64][row_len]
+  int2 *tbl = reinterpret_cast<int2 *>(lds + 2 * GC_C * row_len);   // [ltot][V] (nbr, coef)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int g = lane >> 4;                  // frame within the tile / MFMA k index
+  const int g = lane >> 4;                            // joint within the group of 4 / MFMA k index
   const int r = lane & 15;
+  const int nt = wave & 3;                            // 16 ci columns owned by this wave
+  const int half = wave >> 2;                         // which plane set
+
+  for (int e = tid; e < ltot * p.V; e += DW_THREADS)
+    tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
 
   const int tiles_per_seq = (p.T + DW_F - 1) / DW_F;
   const int total_tiles = n_seq * tiles_per_seq;
   const size_t row_stride = (size_t)p.T * p.V;
+  const int n_groups = (p.V + 3) / 4;
 
-  floatx4 acc[KP][4];
+  floatx4 acc[DW_PL][4];
 #pragma unroll
-  for (int k = 0; k < KP; ++k)
+  for (int kk = 0; kk < DW_PL; ++kk)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[k][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 4; ++m) acc[kk][m] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int seq = tile / tiles_per_seq;
@@ -268,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void gcn_dw_kernel(GcnParams p, int n_seq, 
     const int ncols = min(DW_F, p.T - t0) * p.V;
     const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    __syncthreads();  // previous tile fully consumed
-    for (int c = wave; c < GC_C; c += 4) {
+    __syncthreads();  // previous tile fully consumed (and the table written, first time)
+    for (int c = wave; c < GC_C; c += DW_THREADS / 64) {
       const float *sx = xg + (size_t)c * row_stride;
       const float *sd = dg + (size_t)c * row_stride;
       for (int q = lane; q < DW_F * p.V; q += 64) {
@@ -280,35 +356,61 @@ __global__ __launch_bounds__(256, 1) void gcn_dw_kernel(GcnParams p, int n_seq, 
     }
     __syncthreads();
 
-    const float *xrow = xs + (16 * wave + r) * row_len + g * p.V;   // this lane's ci row, frame g
-    const float *drow = dzs + r * row_len + g * p.V;                 // + 16*m rows
-    for (int w = 0; w < p.V; ++w) {
-      float a[4];
+    const float *xrow = xs + (16 * nt + r) * row_len;   // this lane's ci row
+    const float *drow = dzs + r * row_len;               // + 16*m rows
+    for (int wg = 0; wg < n_groups; ++wg) {
+      const int w = 4 * wg + g;
+      const bool live = w < p.V;
+      const int wc = live ? w : 0;
+      float a[4][DW_F];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) a[m] = drow[16 * m * row_len + w];
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        const int L = p.Lk[k];
-        const int base = p.Lofs[k] * p.V + w;
-        float b = 0.f;
-        for (int j = 0; j < L; ++j) b = fmaf(coef[base + j * p.V], xrow[nbr[base + j * p.V]], b);
+        for (int f = 0; f < DW_F; ++f) a[m][f] = live ? drow[16 * m * row_len + f * p.V + wc] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[k][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[k][m], 0, 0, 0);
+      for (int kk = 0; kk < DW_PL; ++kk) {
+        const int k = sets.plane[half][kk];
+        if (k < 0) continue;                             // uniform
+        float b[DW_F];
+        const int2 *trow = tbl + p.Lofs[k] * p.V + wc;
+        switch (p.Lk[k]) {
+          case 1: dw_plane<1>(trow, p.V, xrow, p.V, live, b); break;
+          case 2: dw_plane<2>(trow, p.V, xrow, p.V, live, b); break;
+          case 3: dw_plane<3>(trow, p.V, xrow, p.V, live, b); break;
+          case 4: dw_plane<4>(trow, p.V, xrow, p.V, live, b); break;
+          case 5: dw_plane<5>(trow, p.V, xrow, p.V, live, b); break;
+          case 6: dw_plane<6>(trow, p.V, xrow, p.V, live, b); break;
+          case 7: dw_plane<7>(trow, p.V, xrow, p.V, live, b); break;
+          case 8: dw_plane<8>(trow, p.V, xrow, p.V, live, b); break;
+          case 9: dw_plane<9>(trow, p.V, xrow, p.V, live, b); break;
+          case 10: dw_plane<10>(trow, p.V, xrow, p.V, live, b); break;
+          case 11: dw_plane<11>(trow, p.V, xrow, p.V, live, b); break;
+          default: dw_plane<12>(trow, p.V, xrow, p.V, live, b); break;
+        }
+#pragma unroll
+        for (int f = 0; f < DW_F; ++f)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[kk][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f], b[f], acc[kk][m], 0, 0, 0);
       }
     }
   }
 
-  // partial[block][k][c][ci]: D[row = 4*g + reg][col = r] -> c = 16*m + row, ci = 16*wave + r
-  float *out = dw_partial + (size_t)blockIdx.x * KP * GC_C * GC_C;
+  // partial[block][k][c][ci]: D[row = 4*g + q][col = r] -> c = 16*m + row, ci = 16*nt + r
+  float *out = dw_partial + (size_t)blockIdx.x * p.K * GC_C * GC_C;
 #pragma unroll
-  for (int k = 0; k < KP; ++k)
+  for (int kk = 0; kk < DW_PL; ++kk) {
+    const int k = sets.plane[half][kk];
+    if (k < 0) continue;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        out[((size_t)k * GC_C + 16 * m + 4 * g + q) * GC_C + 16 * wave + r] = acc[k][m][q];
+        out[((size_t)k * GC_C + 16 * m + 4 * g + q) * GC_C + 16 * nt + r] = acc[kk][m][q];
+  }
 }
+
+}  // namespace
 
 // =============================================================================
 // Adjacency gradient at the non-zero entries:
@@ -320,6 +422,8 @@ __global__ __launch_bounds__(256, 1) void gcn_dw_kernel(GcnParams p, int n_seq, 
 // partial products are reduced with LDS float atomics into a [sum L_k][V] table that
 // each persistent workgroup writes out once.
 // =============================================================================
+namespace {
+
 constexpr int DC_NT = 6;  // n-tiles per wave (two waves share the same columns, one per row half)
 
 __global__ __launch_bounds__(256, 1) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
@@ -439,20 +543,36 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   GcnParams p;
   const int ltot = gcn_fill_params(p, T, V, K, Lk_host, DW_F);
   if (ltot < 0) return ltot;
-  if (K != DW_MAXK || N < 0 || n_blocks < 1) return P2R_EINVAL;
+  if (K > 2 * DW_PL || N < 0 || n_blocks < 1) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  const int row_len = DW_F * V + ((DW_F * V) % 2 == 0 ? 1 : 0);  // odd row length
-  const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float);
+  // two plane sets with balanced gather work (longest lists first, greedy)
+  DwSets sets;
+  int cnt[2] = {0, 0}, load[2] = {0, 0}, order[GC_MAXK];
+  for (int k = 0; k < K; ++k) order[k] = k;
+  for (int i = 0; i < K; ++i)
+    for (int j = i + 1; j < K; ++j)
+      if (p.Lk[order[j]] > p.Lk[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < DW_PL; ++i) sets.plane[h][i] = -1;
+  for (int i = 0; i < K; ++i) {
+    int h = (load[0] <= load[1]) ? 0 : 1;
+    if (cnt[h] >= DW_PL) h ^= 1;
+    sets.plane[h][cnt[h]++] = order[i];
+    load[h] += p.Lk[order[i]] + 4;   // gathers + the 16 MFMAs a plane costs per frame group
+  }
+  int row_len = DW_F * V;
+  while (row_len % 32 != 2) ++row_len;   // row stride == 2 (mod 32): conflict-free column reads
+  const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2);
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)gcn_dw_kernel<DW_MAXK>,
+    hipError_t e = hipFuncSetAttribute((const void *)gcn_dw_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gcn_dw_kernel<DW_MAXK>, dim3(n_blocks), dim3(256), lds, p2r_stream(stream), p, N,
-                     row_len, x, dz, nbr, coef, dw_partial);
+  hipLaunchKernelGGL(gcn_dw_kernel, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
+                     row_len, ltot, x, dz, nbr, coef, dw_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
