@@ -424,27 +424,54 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 // =============================================================================
 namespace {
 
-constexpr int DC_NT = 6;  // n-tiles per wave (two waves share the same columns, one per row half)
+constexpr int DC_THREADS = 512;
 
-__global__ __launch_bounds__(256, 1) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
-                                                           const float *__restrict__ x,
-                                                           const float *__restrict__ dz,
-                                                           const float *__restrict__ Wt,
-                                                           const uint8_t *__restrict__ nbr,
-                                                           float *__restrict__ dcoef_partial) {
+// Per-lane partial of dcoef for one (plane, n-tile): sum over this lane's 16 rows of
+// H[row][col] * X[row][(frame, neighbour_j)], for each of the L neighbours; reduced over
+// the four lane groups with LDS float atomics.
+template <int L>
+__device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float *__restrict__ xs, int g,
+                                          const int2 *__restrict__ trow, int V, int fbase,
+                                          float *__restrict__ dcs_row) {
+  int nb[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) nb[j] = trow[j * V].x;
+  float part[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) part[j] = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float *xr = xs + (16 * m + 4 * g + q) * GC_ROW + fbase;
+#pragma unroll
+      for (int j = 0; j < L; ++j) part[j] = fmaf(h[m][q], xr[nb[j]], part[j]);
+    }
+#pragma unroll
+  for (int j = 0; j < L; ++j) atomicAdd(dcs_row + j * V, part[j]);
+}
+
+__global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
+                                                                  const float *__restrict__ x,
+                                                                  const float *__restrict__ dz,
+                                                                  const float *__restrict__ Wt,
+                                                                  const uint8_t *__restrict__ nbr,
+                                                                  float *__restrict__ dcoef_partial) {
   extern __shared__ float lds[];
-  float *xs = lds;                          // [64][GC_NP]
-  float *dcs = lds + GC_C * GC_NP;          // [ltot][V]
+  float *xs = lds;                                                   // [64][GC_ROW]
+  int2 *tbl = reinterpret_cast<int2 *>(lds + GC_C * GC_ROW);         // [ltot][V] (nbr, unused)
+  float *dcs = reinterpret_cast<float *>(tbl + ltot * p.V);          // [ltot][V]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int mt = wave & 1;                  // row half (ci) of H owned by this wave
-  const int ntb = (wave >> 1) * DC_NT;      // first n-tile
+  const int g = lane >> 4;
+  const int r = lane & 15;
 
-  for (int q = tid; q < ltot * p.V; q += 256) dcs[q] = 0.f;
+  for (int e = tid; e < ltot * p.V; e += DC_THREADS) {
+    tbl[e] = make_int2((int)nbr[e], 0);
+    dcs[e] = 0.f;
+  }
 
   const int total_tiles = n_seq * p.tiles_per_seq;
   const size_t row_stride = (size_t)p.T * p.V;
@@ -453,60 +480,74 @@ __global__ __launch_bounds__(256, 1) void gcn_dcoef_kernel(GcnParams p, int n_se
     const int seq = tile / p.tiles_per_seq;
     const int t0 = (tile % p.tiles_per_seq) * p.F;
     const int ncols = min(p.F, p.T - t0) * p.V;
-    const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     __syncthreads();
-    for (int c = wave; c < GC_C; c += 4) {
-      const float *src = xg + (size_t)c * row_stride;
-      for (int q = lane; q < GC_NP; q += 64) xs[c * GC_NP + q] = q < ncols ? src[q] : 0.f;
+    for (int c = wave; c < GC_C; c += DC_THREADS / 64) {
+      const float *src = xgm + (size_t)c * row_stride;
+#pragma unroll
+      for (int q0 = 0; q0 < GC_NP; q0 += 64) {
+        const int q = q0 + lane;
+        xs[c * GC_ROW + q] = q < ncols ? src[q] : 0.f;
+      }
     }
 
-    int colv[DC_NT], fbase[DC_NT], wj[DC_NT];
-    bool valid[DC_NT];
-    float bz[DC_NT][32];                    // dZ[c = 32*hi + s][col]: B operands, reused by every plane
+    int fbase[GC_NT16], wj[GC_NT16];
+    bool valid[GC_NT16];
+    float bz[GC_NT16][16];               // dZ[c = 16g + s][col]: B operands, reused by every plane
 #pragma unroll
-    for (int i = 0; i < DC_NT; ++i) {
-      const int col = (ntb + i) * 32 + l31;
-      colv[i] = col;
+    for (int i = 0; i < GC_NT16; ++i) {
+      const int col = (wave * GC_NT16 + i) * 16 + r;
       valid[i] = col < ncols;
       const int f = valid[i] ? col / p.V : 0;
       wj[i] = valid[i] ? col - f * p.V : 0;
       fbase[i] = f * p.V;
 #pragma unroll
-      for (int s = 0; s < 32; ++s)
-        bz[i][s] = valid[i] ? dg[(size_t)(32 * hi + s) * row_stride + col] : 0.f;
+      for (int s = 0; s < 16; ++s)
+        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + col] : 0.f;
     }
     __syncthreads();
 
     for (int k = 0; k < p.K; ++k) {
-      float a[32];                           // Wt[k][ci = 32*mt + l31][c = 32*hi .. +32)
-      const float4 *w0 = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 32 * mt + l31) * GC_C + hi * 32);
+      float a[4][16];                     // Wt[k][ci = 16m + r][c = 16g .. 16g+15]
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 u = w0[q];
-        a[4 * q + 0] = u.x; a[4 * q + 1] = u.y; a[4 * q + 2] = u.z; a[4 * q + 3] = u.w;
+      for (int m = 0; m < 4; ++m) {
+        const float4 *wp = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 u = wp[q];
+          a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
+        }
       }
       const int L = p.Lk[k];
       const int lofs = p.Lofs[k];
 #pragma unroll
-      for (int i = 0; i < DC_NT; ++i) {
-        floatx16 h;
+      for (int i = 0; i < GC_NT16; ++i) {
+        floatx4_t h[4];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) h[q] = 0.f;
+        for (int m = 0; m < 4; ++m) h[m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 32; ++s) h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bz[i][s], h, 0, 0, 0);
-        // h[q] = H_k[ci = 32*mt + (q&3) + 8*(q>>2) + 4*hi][col_i]
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bz[i][s], h[m], 0, 0, 0);
+        // h[m][q] = H_k[ci = 16m + 4g + q][col_i]
         if (valid[i]) {
-          for (int j = 0; j < L; ++j) {
-            const int trow = (lofs + j) * p.V + wj[i];
-            const float *xcol = xs + fbase[i] + (int)nbr[trow];
-            float part = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const int ci = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hi;
-              part = fmaf(h[q], xcol[ci * GC_NP], part);
-            }
-            atomicAdd(&dcs[trow], part);
+          const int2 *trow = tbl + lofs * p.V + wj[i];
+          float *drow = dcs + lofs * p.V + wj[i];
+          switch (L) {
+            case 1: dc_reduce<1>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 2: dc_reduce<2>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 3: dc_reduce<3>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 4: dc_reduce<4>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 5: dc_reduce<5>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 6: dc_reduce<6>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 7: dc_reduce<7>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 8: dc_reduce<8>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 9: dc_reduce<9>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 10: dc_reduce<10>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 11: dc_reduce<11>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            default: dc_reduce<12>(h, xs, g, trow, p.V, fbase[i], drow); break;
           }
         }
       }
@@ -514,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void gcn_dcoef_kernel(GcnParams p, int n_se
   }
   __syncthreads();
   float *out = dcoef_partial + (size_t)blockIdx.x * ltot * p.V;
-  for (int q = tid; q < ltot * p.V; q += 256) out[q] = dcs[q];
+  for (int q = tid; q < ltot * p.V; q += DC_THREADS) out[q] = dcs[q];
 }
 
 }  // namespace
@@ -587,7 +628,7 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
   if (ltot < 0) return ltot;
   if (N < 0 || n_blocks < 1) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  const size_t lds = ((size_t)GC_C * GC_NP + (size_t)ltot * V) * sizeof(float);
+  const size_t lds = (size_t)GC_C * GC_ROW * sizeof(float) + (size_t)ltot * V * (sizeof(int2) + sizeof(float));
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
@@ -596,7 +637,7 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gcn_dcoef_kernel, dim3(n_blocks), dim3(256), lds, p2r_stream(stream), p, N, ltot, x,
+  hipLaunchKernelGGL(gcn_dcoef_kernel, dim3(n_blocks), dim3(DC_THREADS), lds, p2r_stream(stream), p, N, ltot, x,
                      dz, Wt, nbr, dcoef_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;

@@ -1,0 +1,181 @@
+"""Prediction parsing for evaluation, on the device.
+
+Mirror of the reference's net_utils/ap_helper.py:133-255 (`parse_predictions`),
+:257-292 (`parse_groundtruths`), :294-350 (`assembly_pred_map_cls`, mesh-free
+branches) and :402-428 (`assembly_gt_map_cls`): same signatures, same returned dict
+keys, shapes and dtypes (NumPy arrays, as the reference returns), same ordering of
+`batch_pred_map_cls` (class-major, then proposal index).
+
+What changes is where the work happens.  The reference copies the predictions to the
+host and then runs Python loops: `get_3d_box` per proposal (B*K calls), a SciPy
+Delaunay point-in-hull test per box for the far-box filter, a NumPy min/max per box
+for the AABBs and a NumPy NMS per sample.  Here everything up to and including the
+NMS keep mask is tensor math on the GPU in float64 -- oriented boxes from
+(size, heading, centre) in closed form (utils/pc_utils.py:22-27,50-67,
+utils/tools.py:33-51), the far-box test as the closed-form point-in-oriented-box
+predicate the Delaunay test implements, AABBs by min/max over corners -- and one
+batched launch of the HIP NMS kernel (nms.py:41-119).  Only the final results cross
+PCIe, once.
+"""
+import numpy as np
+import torch
+
+from . import nms as nms_hip
+
+# corner order of utils/tools.py:33-51 get_box_corners: signs of (v0, v1, v2)
+_CORNER_SIGNS = [(-1, -1, -1), (+1, -1, -1), (+1, +1, -1), (-1, +1, -1),
+                 (-1, -1, +1), (+1, -1, +1), (+1, +1, +1), (-1, +1, +1)]
+
+
+def softmax(x):
+    """NumPy softmax over the last axis (net_utils/libs.py:75-80)."""
+    probs = np.exp(x - np.max(x, axis=len(x.shape) - 1, keepdims=True))
+    probs /= np.sum(probs, axis=len(x.shape) - 1, keepdims=True)
+    return probs
+
+
+def head2rot_t(heading):
+    """heading (...,) f64 -> rotation matrices (...,3,3) (utils/pc_utils.py:50-67)."""
+    c, s = torch.cos(heading), torch.sin(heading)
+    R = torch.zeros(heading.shape + (3, 3), dtype=heading.dtype, device=heading.device)
+    R[..., 0, 0] = c
+    R[..., 0, 2] = -s
+    R[..., 1, 1] = 1
+    R[..., 2, 0] = s
+    R[..., 2, 2] = c
+    return R
+
+
+def boxes_to_corners(size, heading, center):
+    """size (...,3) f32, heading (...) f64, center (...,3) f32 -> corners (...,8,3) f64.
+    get_3d_box (utils/pc_utils.py:22-27): vectors = diag(size / 2) . R, corners = centre
+    +- v0 +- v1 +- v2.  `size / 2` is evaluated in float32 like NumPy does there."""
+    half = (size / 2.).to(torch.float64)
+    vectors = half.unsqueeze(-1) * head2rot_t(heading)            # (...,3,3): row i = half_i * R[i]
+    signs = torch.tensor(_CORNER_SIGNS, dtype=torch.float64, device=size.device)   # (8,3)
+    c = center.to(torch.float64).unsqueeze(-2)                    # (...,1,3)
+    # reference order: ((centre +- v0) +- v1) +- v2
+    out = c + signs[:, 0, None] * vectors[..., None, 0, :]
+    out = out + signs[:, 1, None] * vectors[..., None, 1, :]
+    out = out + signs[:, 2, None] * vectors[..., None, 2, :]
+    return out
+
+
+def _far_box_mask(pred_size, pred_heading, pred_center, hips, contact_dist):
+    """nonempty mask (B,K): box size sane and at least one hip position inside the box
+    enlarged by `contact_dist` on every half-extent (ap_helper.py:183-196; the reference
+    tests membership in the convex hull of the enlarged box's corners)."""
+    ok_size = ~((pred_size < 0.01).any(-1) | (pred_size > 10).any(-1))
+    R = head2rot_t(pred_heading)                                                      # (B,K,3,3)
+    half = (pred_size / 2. + contact_dist).to(torch.float64)                            # (B,K,3)
+    rel = hips.to(torch.float64)[:, None, :, :] - pred_center.to(torch.float64)[:, :, None, :]   # (B,K,T,3)
+    local = torch.einsum('bktd,bkid->bkti', rel, R)                                     # coords along the box axes
+    inside = (local.abs() <= half[:, :, None, :]).all(-1).any(-1)
+    return ok_size & inside
+
+
+def parse_predictions(est_data, gt_data, config_dict, return_device=False):
+    """est_data: end_points of `P2RNet.generate`; gt_data: batch (needs 'input_joints' when
+    remove_far_box).  Returns (eval_dict{'pred_mask' (B,K) uint8}, parsed{'pred_corners_3d'
+    (B,K,8,3) f64, 'sem_cls_probs' (B,K,C) f32, 'obj_prob' (B,K) f32, 'pred_sem_cls' (B,K) i64})."""
+    dataset_config = config_dict['dataset_config']
+    pred_center = est_data['center'].detach()
+    pred_size = torch.exp(est_data['size']).detach()
+    pred_sin_cos = est_data['heading'].detach()
+    pred_heading = torch.atan2(pred_sin_cos[..., 0], pred_sin_cos[..., 1])              # f64
+
+    sem_scores = est_data['sem_cls_scores'].detach()
+    if config_dict['sample_cls']:
+        sem_cls_probs_t = torch.softmax(sem_scores, dim=-1)
+        pred_sem_cls_t = torch.distributions.Categorical(sem_cls_probs_t).sample()
+    else:
+        pred_sem_cls_t = torch.argmax(sem_scores, -1)
+        sem_cls_probs_t = None
+    obj_logits = est_data['objectness_scores'].detach()
+    obj_shift = obj_logits - obj_logits.max(-1, keepdim=True).values                   # libs.softmax, on device
+    obj_e = torch.exp(obj_shift)
+    obj_prob_t = (obj_e / obj_e.sum(-1, keepdim=True))[:, :, 1]                          # (B,K) f32
+
+    corners = boxes_to_corners(pred_size, pred_heading, pred_center)                    # (B,K,8,3) f64
+    bsize, K = pred_center.shape[0], pred_center.shape[1]
+
+    nonempty = torch.ones((bsize, K), dtype=torch.bool, device=pred_center.device)
+    if config_dict['remove_far_box']:
+        hips = gt_data['input_joints'][:, :, dataset_config.origin_joint_id, 0:3]
+        nonempty = _far_box_mask(pred_size, pred_heading, pred_center, hips.to(pred_center.device),
+                                 dataset_config.contact_dist_thresh)
+
+    mins = corners.min(dim=2).values
+    maxs = corners.max(dim=2).values
+    score = obj_prob_t.to(torch.float64).unsqueeze(-1)
+    if not config_dict['use_3d_nms']:
+        # 2D (x,z) NMS == 3D NMS on boxes with a unit y extent
+        zeros, ones = torch.zeros_like(mins[..., :1]), torch.ones_like(mins[..., :1])
+        boxes = torch.cat([mins[..., 0:1], zeros, mins[..., 2:3], maxs[..., 0:1], ones, maxs[..., 2:3], score], -1)
+        same_cls = False
+    elif not config_dict['cls_nms']:
+        boxes = torch.cat([mins, maxs, score], -1)
+        same_cls = False
+    else:
+        boxes = torch.cat([mins, maxs, score, pred_sem_cls_t.to(torch.float64).unsqueeze(-1)], -1)
+        same_cls = True
+    keep, _, npick = nms_hip.nms_3d_batched(boxes.contiguous(), config_dict['nms_iou'],
+                                            config_dict['use_old_type_nms'], same_cls, valid=nonempty,
+                                            return_pick=True)
+    assert bool((npick > 0).all()), "NMS kept no box for some sample (reference: assert len(pick) > 0)"
+
+    if return_device:
+        return {'pred_mask': keep}, {'pred_corners_3d': corners, 'obj_prob': obj_prob_t,
+                                     'pred_sem_cls': pred_sem_cls_t, 'sem_cls_scores': sem_scores}
+    if sem_cls_probs_t is None:
+        sem_cls_probs = softmax(sem_scores.cpu().numpy())
+    else:
+        sem_cls_probs = sem_cls_probs_t.cpu().numpy()
+    return ({'pred_mask': keep.cpu().numpy()},
+            {'pred_corners_3d': corners.cpu().numpy(), 'sem_cls_probs': sem_cls_probs,
+             'obj_prob': obj_prob_t.cpu().numpy(), 'pred_sem_cls': pred_sem_cls_t.cpu().numpy()})
+
+
+def parse_groundtruths(gt_data, config_dict):
+    """GT boxes -> corners (ap_helper.py:257-292); masked-out slots stay zero."""
+    gt_center = gt_data['center_label'][:, :, 0:3].detach()
+    gt_size = torch.exp(gt_data['size']).detach()
+    gt_heading = torch.atan2(gt_data['heading'][..., 0], gt_data['heading'][..., 1]).detach()
+    mask = gt_data['box_label_mask'].detach()
+    corners = boxes_to_corners(gt_size, gt_heading.to(torch.float64), gt_center)
+    corners = corners * (mask != 0).to(torch.float64)[:, :, None, None]
+    return {'sem_cls_label': gt_data['sem_cls_label'], 'gt_corners_3d': corners.cpu().numpy(),
+            'box_label_mask': mask.cpu().numpy()}
+
+
+def assembly_pred_map_cls(eval_dict, parsed_predictions, config_dict, mesh_outputs=None, voxel_size=0.047):
+    """Per sample list of (class, corners (8,3), confidence) (ap_helper.py:294-350)."""
+    assert mesh_outputs is None, "mesh evaluation is outside the hot path"
+    pred_corners_3d = parsed_predictions['pred_corners_3d']
+    sem_cls_probs = parsed_predictions['sem_cls_probs']
+    obj_prob = parsed_predictions['obj_prob']
+    pred_mask = eval_dict['pred_mask']
+    pred_sem_cls = parsed_predictions['pred_sem_cls']
+    bsize, n_prop = pred_sem_cls.shape
+    out = []
+    for i in range(bsize):
+        keep = [j for j in range(n_prop) if pred_mask[i, j] == 1 and obj_prob[i, j] > config_dict['conf_thresh']]
+        if config_dict['per_class_proposal']:
+            cur = []
+            for ii in range(config_dict['dataset_config'].num_class):
+                cur += [(ii, pred_corners_3d[i, j], sem_cls_probs[i, j, ii] * obj_prob[i, j]) for j in keep]
+        else:
+            cur = [(pred_sem_cls[i, j].item(), pred_corners_3d[i, j], obj_prob[i, j]) for j in keep]
+        out.append(cur)
+    eval_dict['batch_pred_map_cls'] = out
+    return eval_dict
+
+
+def assembly_gt_map_cls(parsed_gts, mesh_outputs=None, voxel_size=0.047):
+    """Per sample list of (class, corners (8,3)) (ap_helper.py:402-428)."""
+    assert mesh_outputs is None, "mesh evaluation is outside the hot path"
+    sem_cls_label = parsed_gts['sem_cls_label']
+    corners = parsed_gts['gt_corners_3d']
+    mask = parsed_gts['box_label_mask']
+    return [[(sem_cls_label[i, j].item(), corners[i, j]) for j in range(corners.shape[1]) if mask[i, j] == 1]
+            for i in range(sem_cls_label.shape[0])]
