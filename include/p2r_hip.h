@@ -160,7 +160,7 @@ int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
 
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65):
  * dw_partial [n_blocks][K][64][64], to be summed over the leading axis by the
- * caller (deterministic).  K must be 11, V <= 64. */
+ * caller (deterministic).  K <= 12, V <= 64. */
 int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host,
                               const float *x, const float *dz,
                               const uint8_t *nbr, const float *coef,
@@ -174,6 +174,30 @@ int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
                             const float *x, const float *dz, const float *Wt,
                             const uint8_t *nbr, int n_blocks,
                             float *dcoef_partial, void *stream);
+
+/* ---- BatchNorm + residual + ReLU of st_gcn_block (stgcn_layers.py:399-439) -------- */
+
+/* per-row partial sums for the batch statistics: x viewed as [rows = N*C][L] ->
+ * partial [rows][2] = (sum x, sum x^2); the caller combines rows of a channel. */
+int p2r_bn_stats(int rows, int L, const float *x, float *partial, void *stream);
+
+/* y = relu?(x * scale[c] + shift[c] + res?)  over x (N,C,L); res may be NULL.
+ * Replaces BatchNorm2d (normalise with given statistics) -> [+ residual] -> ReLU. */
+int p2r_bn_apply(int N, int C, int L, const float *x, const float *scale,
+                 const float *shift, const float *res, int relu, float *y,
+                 void *stream);
+
+/* backward reductions: g = dy * (relu ? y > 0 : 1); partial [N*C][2] =
+ * (sum g, sum g * xhat), xhat = (x - mean[c]) * invstd[c]. */
+int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y,
+                      const float *x, const float *mean, const float *invstd,
+                      int relu, float *partial, void *stream);
+
+/* dx = kscale[c] * (g - m1[c] - xhat * m2[c]); dres = g (dres may be NULL). */
+int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
+                     const float *x, const float *mean, const float *invstd,
+                     const float *kscale, const float *m1, const float *m2,
+                     int relu, float *dx, float *dres, void *stream);
 
 #ifdef __cplusplus
 }

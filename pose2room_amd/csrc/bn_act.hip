@@ -1,0 +1,229 @@
+// bn_act.hip -- BatchNorm (train / eval) fused with residual add and ReLU, gfx950.
+//
+// Replaces, inside st_gcn_block (reference models/p2rnet/modules/stgcn_layers.py:399-439),
+// the chains  BatchNorm2d -> ReLU  (tcn.0, tcn.1)  and
+// BatchNorm2d -> Dropout(0) -> (+ residual) -> ReLU  (tcn.3, tcn.4, :437-439), which run as
+// 3-5 separate HBM passes each way in the reference (MIOpen BN + elementwise kernels).
+//
+// MI355X design: HBM bound, so the only lever is the number of passes over the
+// (N, C, L = T*V) activation.  Forward = one reduction pass (per-row partial sums, 16-byte
+// loads, one workgroup per (n, c) row so the grid fills the chip) + one apply pass that
+// normalises, adds the residual and applies ReLU in registers.  Backward = one reduction
+// pass (sum g and sum g*xhat with the ReLU mask recomputed from y) + one apply pass
+// producing dx and the residual gradient together.  Partial sums are written per row and
+// combined by the caller in fp64 (deterministic, no atomics).
+#include "p2r_common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void block_sum2(float &a, float &b) {
+  __shared__ float sa[BN_THREADS / 64], sb[BN_THREADS / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  a = 0.f; b = 0.f;
+#pragma unroll
+  for (int i = 0; i < BN_THREADS / 64; ++i) { a += sa[i]; b += sb[i]; }
+}
+
+// partial[row] = (sum x, sum x^2) over the row of length L.
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int L, const float *__restrict__ x,
+                                                              float2 *__restrict__ partial) {
+  const float *row = x + (size_t)blockIdx.x * L;
+  float s = 0.f, q = 0.f;
+  const bool vec = ((uintptr_t)row % 16 == 0);
+  const int L4 = vec ? (L >> 2) : 0;
+  const float4 *r4 = reinterpret_cast<const float4 *>(row);
+  for (int i = threadIdx.x; i < L4; i += BN_THREADS) {
+    const float4 v = r4[i];
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  for (int i = (L4 << 2) + threadIdx.x; i < L; i += BN_THREADS) {
+    const float v = row[i];
+    s += v; q += v * v;
+  }
+  block_sum2(s, q);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_float2(s, q);
+}
+
+// y = relu?(x * scale[c] + shift[c] + res)
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int chunks,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              const float *__restrict__ res,
+                                                              float *__restrict__ y) {
+  const int rowi = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
+  const int c = rowi % C;
+  const float sc = scale[c], sh = shift[c];
+  const size_t base = (size_t)rowi * L;
+  const int per = (((L + chunks - 1) / chunks) + 3) & ~3;   // multiple of 4: chunk starts stay 16-byte aligned
+  const int lo = chunk * per, hi = min(L, lo + per);
+  const bool vec = (((uintptr_t)(x + base) | (uintptr_t)(y + base) | (RES ? (uintptr_t)(res + base) : 0)) % 16 == 0) &&
+                   (lo % 4 == 0);
+  int i = lo + threadIdx.x * 4;
+  if (vec) {
+    for (; i + 3 < hi; i += BN_THREADS * 4) {
+      float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+      v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+      if (RES) {
+        const float4 r = *reinterpret_cast<const float4 *>(res + base + i);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4 *>(y + base + i) = v;
+    }
+    // ragged tail of this chunk: elements [hi - (hi-lo)%4, hi)
+    const int tail = lo + ((hi - lo) & ~3);
+    for (int j = tail + threadIdx.x; j < hi; j += BN_THREADS) {
+      float v = fmaf(x[base + j], sc, sh);
+      if (RES) v += res[base + j];
+      if (RELU) v = fmaxf(v, 0.f);
+      y[base + j] = v;
+    }
+  } else {
+    for (int j = lo + threadIdx.x; j < hi; j += BN_THREADS) {
+      float v = fmaf(x[base + j], sc, sh);
+      if (RES) v += res[base + j];
+      if (RELU) v = fmaxf(v, 0.f);
+      y[base + j] = v;
+    }
+  }
+}
+
+// partial[row] = (sum g, sum g * xhat),  g = dy * (RELU ? y > 0 : 1),  xhat = (x - mean) * invstd
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L, const float *__restrict__ dy,
+                                                                   const float *__restrict__ y,
+                                                                   const float *__restrict__ x,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ invstd,
+                                                                   float2 *__restrict__ partial) {
+  const int c = blockIdx.x % C;
+  const float mu = mean[c], is = invstd[c];
+  const size_t base = (size_t)blockIdx.x * L;
+  float s = 0.f, q = 0.f;
+  const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (RELU ? (uintptr_t)(y + base) : 0)) % 16 == 0);
+  const int L4 = vec ? (L >> 2) : 0;
+  for (int i = threadIdx.x; i < L4; i += BN_THREADS) {
+    float4 g = reinterpret_cast<const float4 *>(dy + base)[i];
+    const float4 xv = reinterpret_cast<const float4 *>(x + base)[i];
+    if (RELU) {
+      const float4 yv = reinterpret_cast<const float4 *>(y + base)[i];
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    s += (g.x + g.y) + (g.z + g.w);
+    q += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+  }
+  for (int i = (L4 << 2) + threadIdx.x; i < L; i += BN_THREADS) {
+    float g = dy[base + i];
+    if (RELU) g = y[base + i] > 0.f ? g : 0.f;
+    s += g; q += g * ((x[base + i] - mu) * is);
+  }
+  block_sum2(s, q);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_float2(s, q);
+}
+
+// dx = k[c] * (g - m1[c] - xhat * m2[c]);  dres = g
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, int chunks,
+                                                                  const float *__restrict__ dy,
+                                                                  const float *__restrict__ y,
+                                                                  const float *__restrict__ x,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ invstd,
+                                                                  const float *__restrict__ kscale,
+                                                                  const float *__restrict__ m1,
+                                                                  const float *__restrict__ m2,
+                                                                  float *__restrict__ dx,
+                                                                  float *__restrict__ dres) {
+  const int rowi = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
+  const int c = rowi % C;
+  const float mu = mean[c], is = invstd[c], kk = kscale[c], a1 = m1[c], a2 = m2[c];
+  const size_t base = (size_t)rowi * L;
+  const int per = (((L + chunks - 1) / chunks) + 3) & ~3;   // multiple of 4: chunk starts stay 16-byte aligned
+  const int lo = chunk * per, hi = min(L, lo + per);
+  for (int j = lo + threadIdx.x; j < hi; j += BN_THREADS) {
+    float g = dy[base + j];
+    if (RELU) g = y[base + j] > 0.f ? g : 0.f;
+    const float xh = (x[base + j] - mu) * is;
+    dx[base + j] = kk * (g - a1 - xh * a2);
+    if (RES) dres[base + j] = g;
+  }
+}
+
+}  // namespace
+
+extern "C" int p2r_bn_stats(int rows, int L, const float *x, float *partial /* [rows][2] */, void *stream) {
+  if (rows < 0 || L <= 0) return P2R_EINVAL;
+  if (rows == 0) return P2R_OK;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(BN_THREADS), 0, p2r_stream(stream), L, x,
+                     reinterpret_cast<float2 *>(partial));
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+static int bn_chunks(int rows, int L) {
+  int chunks = 1;
+  while ((long long)rows * chunks < 2048 && (L / (chunks * 2)) >= 4096) chunks *= 2;
+  return chunks;
+}
+
+extern "C" int p2r_bn_apply(int N, int C, int L, const float *x, const float *scale, const float *shift,
+                            const float *res, int relu, float *y, void *stream) {
+  if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  const int rows = N * C, chunks = bn_chunks(rows, L);
+  dim3 grid(rows * chunks), blk(BN_THREADS);
+  hipStream_t st = p2r_stream(stream);
+  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+extern "C" int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y, const float *x,
+                                 const float *mean, const float *invstd, int relu, float *partial,
+                                 void *stream) {
+  if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  hipStream_t st = p2r_stream(stream);
+  if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, reinterpret_cast<float2 *>(partial));
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, reinterpret_cast<float2 *>(partial));
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y, const float *x,
+                                const float *mean, const float *invstd, const float *kscale,
+                                const float *m1, const float *m2, int relu, float *dx, float *dres,
+                                void *stream) {
+  if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  const int rows = N * C, chunks = bn_chunks(rows, L);
+  dim3 grid(rows * chunks), blk(BN_THREADS);
+  hipStream_t st = p2r_stream(stream);
+  if (relu && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
+  else if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
+  else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

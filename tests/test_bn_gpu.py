@@ -1,0 +1,48 @@
+"""GPU: fused BatchNorm(+residual)(+ReLU) kernels against torch.nn.BatchNorm2d."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 40, 53), (3, 8, 7, 5), (4, 64, 128, 53)])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_bn_act(dev, shape, with_res, train):
+    from pose2room_amd.p2rnet import bn_op
+    torch.manual_seed(0)
+    bn_ref = torch.nn.BatchNorm2d(shape[1]).to(dev)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.5, 0.5)
+        bn_ref.running_mean.uniform_(-0.2, 0.2); bn_ref.running_var.uniform_(0.5, 2.0)
+    bn_new = copy.deepcopy(bn_ref)
+    bn_ref.train(train); bn_new.train(train)
+    x = (torch.randn(shape, device=dev) * 2 + 0.5)
+    res = torch.randn(shape, device=dev) if with_res else None
+    go = torch.randn(shape, device=dev)
+
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    yr = bn_ref(xr)
+    if with_res:
+        yr = yr + rr
+    yr = torch.relu(yr)
+    yr.backward(go)
+
+    xn = x.clone().requires_grad_(True)
+    rn = res.clone().requires_grad_(True) if with_res else None
+    yn = bn_op.fused_bn_act(xn, bn_new, rn, relu=True)
+    yn.backward(go)
+
+    torch.testing.assert_close(yn, yr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xn.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    if with_res:
+        torch.testing.assert_close(rn.grad, rr.grad, rtol=1e-5, atol=1e-6)
+    if train:
+        torch.testing.assert_close(bn_new.weight.grad, bn_ref.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bn_new.bias.grad, bn_ref.bias.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bn_new.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn_new.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn_new.num_batches_tracked) == int(bn_ref.num_batches_tracked)
