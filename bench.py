@@ -12,9 +12,10 @@ reduce_dict / .item() of the reference's train_step (models/training.py:25-43).
 Workload = BASELINE.json configs[2]: bs=32 per GPU, T=1024, J=53 (weak scaling).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     -- the step against the fp32 MFMA roof (algorithmic FLOPs of the
-                  reference step / measured step time) and, per HIP kernel, the
-                  event-timed duration at the P2RNet shapes;
+  roofline     -- the dominant kernel (gcn_fused_kernel) against the fp32 MFMA roof:
+                  FLOPs per launch / event-timed launch duration, HBM traffic from PMC;
+  step_roofline-- the whole step with the reference's algorithmic FLOPs;
+  kernels      -- event-timed durations of the other HIP kernels at the P2RNet shapes;
   cpu_baseline -- the same host model on the host cores with the CPU oracle behind
                   the ops ("port"), on a bounded sample.
 """
@@ -56,6 +57,53 @@ def build_trainer(device, frames, world):
     else:
         net = ModuleWrapper(net)
     return Trainer(cfg, net, load_optimizer(cfg.config, net), device), cfg
+
+
+GCN_TRAFFIC_BYTES = 1025853543   # profiles/r1_gcn_pmc_traffic.json: PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE
+
+
+def dominant_kernel_roofline(device, batch, frames):
+    """The step's dominant kernel is gcn_fused_kernel (csrc/stgcn_gcn.hip): 12 launches per
+    step (6 blocks x forward + data gradient).  One launch at the bench shape is timed with
+    events on the stream it is launched on.  FLOPs per launch = what the kernel executes for
+    the reference's conv1x1 + graph einsum: dense 2*64*704 + sparse 2*64*971 per frame-joint
+    column (the reference's dense formulation of the same op is 2*64*704 + 2*64*53*11 per
+    column, reported as `reference_algorithmic_tflops`)."""
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    t = tables.on(device)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 64, frames, V, generator=g).to(device)
+    W = (torch.randn(K * 64, 64, generator=g) / 8).to(device)
+    coef = gcn_tables.coefficients(torch.tensor(A, dtype=torch.float32, device=device), t['gidx_c']).contiguous()
+    bias = torch.zeros(64, V, device=device)
+    fn = lambda: gcn_op._gcn_forward(x, W, t['nbr_c'], coef, tables.LkA_c, bias, tables)
+    for _ in range(3):
+        fn()
+    stream = torch.cuda.current_stream(device)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    cols = batch * frames * V
+    nnz = int((A != 0).sum())
+    flops = (2.0 * 64 * 64 * K + 2.0 * 64 * nnz / V) * cols
+    ref_flops = (2.0 * 64 * 64 * K + 2.0 * 64 * V * K) * cols
+    tf = flops / ms / 1e9
+    scale = cols / float(32 * 1024 * 53)
+    return {'bound': 'mfma', 'kernel': 'gcn_fused_kernel (ST-GCN graph conv: forward and data gradient, 12 launches/step)',
+            'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': int(GCN_TRAFFIC_BYTES * scale),
+            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops,
+            'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
+            'reference_algorithmic_tflops': round(ref_flops / ms / 1e9, 2)}
 
 
 def kernel_microbench(device):
@@ -191,14 +239,14 @@ def main():
                                    f'seeds=512, proposals=128 (BASELINE configs[2])',
                        'global_batch': world * args.batch, 'frames': args.frames,
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
-            'roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS * world,
-                         'unit': 'TFLOP/s', 'frac': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-                         'traffic': None,
-                         'scope': 'whole train step: algorithmic fwd+bwd FLOPs of the reference step '
-                                  f'({gflop_per_sample(args.frames)} GFLOP/sample) / step time'},
+            'roofline': dominant_kernel_roofline(device, args.batch, args.frames),
+            'step_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS * world,
+                              'unit': 'TFLOP/s', 'frac': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                              'scope': 'whole train step: algorithmic fwd+bwd FLOPs of the REFERENCE step '
+                                       f'({gflop_per_sample(args.frames)} GFLOP/sample, dense graph product) / step time'},
         }
         if not args.no_microbench:
-            line['roofline']['kernels'] = kernel_microbench(device)
+            line['kernels'] = kernel_microbench(device)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.frames)
         print(json.dumps(line), flush=True)

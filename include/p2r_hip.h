@@ -199,6 +199,10 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
                      const float *kscale, const float *m1, const float *m2,
                      int relu, float *dx, float *dres, void *stream);
 
+/* per-row column sums: x viewed as [rows][T][V] -> out_partial [rows][V] = sum over T
+ * (gradient of the graph-conv bias table; the caller sums rows of a channel). */
+int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,3 +227,36 @@ extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const floa
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
+
+// ---- per-(channel, joint) sums over samples and frames -------------------------------
+// out_partial[row][w] = sum_t x[row][t*V + w]   (row = (n, c)); the caller sums over n.
+// Used for the gradient of the graph-conv bias term (a (C, V) table).
+namespace {
+__global__ __launch_bounds__(256) void colsum_kernel(int T, int V, const float *__restrict__ x,
+                                                     float *__restrict__ out_partial) {
+  __shared__ float s_acc[256];
+  const float *row = x + (size_t)blockIdx.x * T * V;
+  const int lanes_used = (256 / V) * V;          // whole frames per sweep
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  if (tid < lanes_used) {
+    const int stride = lanes_used;                // multiple of V: every thread keeps its joint
+    for (int i = tid; i < T * V; i += stride) acc += row[i];
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < V) {
+    float s = 0.f;
+    for (int j = tid; j < lanes_used; j += V) s += s_acc[j];
+    out_partial[(size_t)blockIdx.x * V + tid] = s;
+  }
+}
+}  // namespace
+
+extern "C" int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream) {
+  if (rows < 0 || T <= 0 || V <= 0 || V > 256) return P2R_EINVAL;
+  if (rows == 0) return P2R_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3(rows), dim3(256), 0, p2r_stream(stream), T, V, x, out_partial);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

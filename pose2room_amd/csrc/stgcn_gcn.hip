@@ -35,8 +35,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int GC_C = 64;        // channels (in == out for every P2RNet block)
 constexpr int GC_NP = 384;      // padded tile width (columns) = 12 MFMA n-tiles of 32
-constexpr int GC_NT_PER_WAVE = 3;
-constexpr int GC_WAVES = 4;
 constexpr int GC_MAXK = 16;
 constexpr int GC_MAXL = 12;     // longest neighbour list supported per (plane, column)
 
@@ -158,9 +156,10 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   for (int k = 0; k < p.K; ++k) {
     // A operands: W_k[row 16m + r][channels 16g .. 16g+15]
     float a[4][16];
+    const int kw = k;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
+      const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)kw * GC_C + 16 * m + r) * GC_C + 16 * g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 u = wp[q];
@@ -182,15 +181,13 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
       }
       switch (L) {
         case 1: agg_mfma16<1>(xg, off, cf, a, acc[i]); break;
-        case 2: agg_mfma16<2>(xg, off, cf, a, acc[i]); break;
+        case 2:
         case 3: agg_mfma16<3>(xg, off, cf, a, acc[i]); break;
-        case 4: agg_mfma16<4>(xg, off, cf, a, acc[i]); break;
+        case 4:
         case 5: agg_mfma16<5>(xg, off, cf, a, acc[i]); break;
-        case 6: agg_mfma16<6>(xg, off, cf, a, acc[i]); break;
+        case 6:
         case 7:
         case 8: agg_mfma16<8>(xg, off, cf, a, acc[i]); break;
-        case 9:
-        case 10: agg_mfma16<10>(xg, off, cf, a, acc[i]); break;
         default: agg_mfma16<12>(xg, off, cf, a, acc[i]); break;
       }
     }

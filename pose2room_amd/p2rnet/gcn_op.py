@@ -94,7 +94,10 @@ class _GraphConv(Function):
                     _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
                 dcoef = part.sum(0)
         if ctx.needs_input_grad[4]:
-            dbias = dz.sum(dim=(0, 2))                                 # (C, V)
+            part = torch.empty((N * C, V), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")
+            dbias = part.view(N, C, V).sum(0)                          # (C, V)
         return dx, dW, dcoef, None, dbias, None
 
 
