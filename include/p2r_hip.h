@@ -203,6 +203,20 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */
 int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream);
 
+/* ---- fused vote aggregation (inference) ----------------------------------------------- */
+
+/* replaces the chain ball_query -> group_points(features) -> [Conv2d 1x1 + ReLU] x2 ->
+ * max over nsample of PointnetSAModuleVotes.forward (pointnet2_modules.py:220-259 with
+ * mlp=[256,256,256], bn=False, use_xyz=False, pooling='max') in one launch, forward only.
+ * xyz (b,n,3), new_xyz (b,m,3), features (b,256,n), w1 (256,256), b1 (256), w2 (256,256),
+ * b2 (256) -> idx (b,m,16) i32 (identical to p2r_ball_query), out (b,256,m) f32.
+ * nsample must be 16 and C0 = C1 = C2 = 256. */
+int p2r_sa_votes_forward(int b, int n, int m, int nsample, float radius, int C0,
+                         int C1, int C2, const float *xyz, const float *new_xyz,
+                         const float *features, const float *w1, const float *b1,
+                         const float *w2, const float *b2, int *idx, float *out,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,11 +11,11 @@ radius=0.3, nsample=16, mlp=[256,256,256], use_xyz=False, normalize_xyz=True,
 bn=False)` (models/p2rnet/modules/proposal_net.py:63-71) -- the others are kept
 for the pointnet2_ops call surface.
 
-When the configuration allows it (`fused=True`, the default, and bn=False,
-use_xyz=False, pooling='max', no uniform re-sampling) `PointnetSAModuleVotes`
-replaces the chain ball_query -> group(xyz) -> group(features) -> 2x(conv1x1 +
-ReLU) -> max-pool by one fused op (`pose2room_amd.pointnet2_ops.fused`), which
-returns the same tensors.
+With autograd off (the evaluation path) and a configuration that allows it (`fused=True`,
+bn=False, use_xyz=False, pooling='max', 256-wide two-layer MLP, nsample=16)
+`PointnetSAModuleVotes` replaces the chain ball_query -> group(xyz) -> group(features) ->
+2x(conv1x1 + ReLU) -> max-pool by one fused MFMA kernel (`pose2room_amd.pointnet2_ops.fused`),
+which returns the same tensors.
 """
 from typing import List, Optional, Tuple
 
@@ -136,7 +136,7 @@ class PointnetSAModuleVotes(nn.Module):
 
     def _can_fuse(self, features):
         from . import fused as fused_ops
-        return (self.fused and fused_ops.available() and self.npoint is not None
+        return (self.fused and not torch.is_grad_enabled() and fused_ops.available() and self.npoint is not None
                 and not self.bn and not self.use_xyz
                 and self.pooling == 'max' and not self.sample_uniformly and not self.ret_unique_cnt
                 and features is not None and features.is_cuda and len(self.mlp_module) == 4

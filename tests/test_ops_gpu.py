@@ -161,3 +161,30 @@ def test_nms3d_batched_with_valid_mask(oracle, dev):
         assert list(pick[i, :npick[i]]) == want
         mask = np.zeros(K, np.uint8); mask[want] = 1
         assert np.array_equal(keep[i], mask)
+
+
+@pytest.mark.parametrize("B,N,M,kind", [(2, 512, 128, "walk"), (1, 300, 37, "uniform"), (3, 64, 6, "lattice")])
+def test_sa_votes_fused_forward(ext, oracle, dev, B, N, M, kind):
+    """Fused ball-query + group + MLP + max kernel vs the unfused HIP chain / oracle indices."""
+    from pose2room_amd.pointnet2_ops import fused
+    from pose2room_amd.pointnet2_ops.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(B * 7 + M)
+    mod = PointnetSAModuleVotes(npoint=M, radius=0.3, nsample=16, mlp=[256, 256, 256], use_xyz=False,
+                                normalize_xyz=True, bn=False).to(dev)
+    xyz = cases.cloud(B, N, 11, kind)
+    feats = torch.randn(B, 256, N)
+    new_xyz = cases.centres_from(xyz, M, 11)
+    out, idx = fused.sa_votes(xyz.to(dev), new_xyz.to(dev), feats.to(dev), 0.3, 16, mod.mlp_module, return_idx=True)
+    assert torch.equal(idx.cpu(), oracle.OracleExt.ball_query(new_xyz, xyz, 0.3, 16))
+    with torch.no_grad():
+        grouped = ext.group_points(feats.to(dev), idx)
+        want = mod.mlp_module(grouped).max(dim=3).values
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4)
+    # the module takes the fused path when autograd is off and returns the same tensors
+    with torch.no_grad():
+        nx, nf, inds = mod(xyz.to(dev), feats.to(dev))
+    mod.fused = False
+    with torch.no_grad():
+        nx2, nf2, inds2 = mod(xyz.to(dev), feats.to(dev))
+    assert torch.equal(inds, inds2) and torch.equal(nx, nx2)
+    torch.testing.assert_close(nf, nf2, rtol=1e-4, atol=1e-4)
