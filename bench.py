@@ -151,8 +151,10 @@ def cpu_baseline(frames, budget_s=25.0):
     """The same host model on the host cores, CPU oracle behind the ops ("port")."""
     from oracle.cpu_backend import cpu_ops
     from pose2room_amd.p2rnet.synthetic import make_batch
-    cores = torch.get_num_threads()
-    dev = torch.device('cpu')
+    # oneDNN / OpenMP scale poorly past ~32 threads at this batch size: use at most 32 cores
+    prev_threads = torch.get_num_threads()
+    cores = min(os.cpu_count() or prev_threads, 32)
+    torch.set_num_threads(cores)
     trainer, _ = build_trainer_cpu(frames)
     B = 2
     batch = make_batch(B, frames, seed=1234)
@@ -165,6 +167,7 @@ def cpu_baseline(frames, budget_s=25.0):
             trainer.train_step(dict(batch))
             n += 1
         dt = (time.time() - t0) / n
+    torch.set_num_threads(prev_threads)
     return {'value': round(B / dt, 4), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} train steps of bs={B}, T={frames}, J=53 after 1 warm-up (host model + CPU oracle ops)'}
 
