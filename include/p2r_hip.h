@@ -187,17 +187,36 @@ int p2r_bn_apply(int N, int C, int L, const float *x, const float *scale,
                  const float *shift, const float *res, int relu, float *y,
                  void *stream);
 
-/* backward reductions: g = dy * (relu ? y > 0 : 1); partial [N*C][2] =
- * (sum g, sum g * xhat), xhat = (x - mean[c]) * invstd[c]. */
+/* backward reductions: g = dy * mask, mask by `relu`: 0 none, 1 (y > 0), 2 recomputed
+ * (x * mscale[c] + mshift[c] > 0); partial [N*C][2] = (sum g, sum g * xhat),
+ * xhat = (x - mean[c]) * invstd[c]. */
 int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y,
                       const float *x, const float *mean, const float *invstd,
-                      int relu, float *partial, void *stream);
+                      int relu, const float *mscale, const float *mshift,
+                      float *partial, void *stream);
 
 /* dx = kscale[c] * (g - m1[c] - xhat * m2[c]); dres = g (dres may be NULL). */
 int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
                      const float *x, const float *mean, const float *invstd,
                      const float *kscale, const float *m1, const float *m2,
-                     int relu, float *dx, float *dres, void *stream);
+                     int relu, const float *mscale, const float *mshift,
+                     float *dx, float *dres, void *stream);
+
+/* ---- temporal (3,1) convolution of st_gcn_block, BatchNorm+ReLU fused on the input ---- */
+
+/* replaces tcn.0-tcn.2 (stgcn_layers.py:399-411): out[n,c,t,w] = bias[c] + sum_p sum_ci
+ * W[p][c][ci] * h[n,ci,t+p-1,w], h = relu(x*scale+shift) when scale != NULL else x, zero
+ * outside [0,T).  x, out (N,64,T,V); W [3][64][64]; scale/shift/bias [64] or NULL.  With
+ * the taps reversed and transposed it yields the data gradient. */
+int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, const float *scale,
+                            const float *shift, const float *W, const float *bias,
+                            float *out, void *stream);
+
+/* weight gradient: dw_partial [n_blocks][3][64][64] (summed by the caller) of
+ * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-1,w] with h as above. */
+int p2r_stgcn_tconv_weight_grad(int N, int T, int V, const float *x, const float *scale,
+                                const float *shift, const float *dout, int n_blocks,
+                                float *dw_partial, void *stream);
 
 /* per-row column sums: x viewed as [rows][T][V] -> out_partial [rows][V] = sum over T
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */

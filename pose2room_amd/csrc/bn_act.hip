@@ -105,15 +105,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
 }
 
 // partial[row] = (sum g, sum g * xhat),  g = dy * (RELU ? y > 0 : 1),  xhat = (x - mean) * invstd
-template <bool RELU>
+// MASK: 0 = no ReLU, 1 = ReLU mask from the saved output y (> 0), 2 = ReLU mask recomputed
+// from the input (x * mscale[c] + mshift[c] > 0; the normalised activation was never stored).
+template <int MASK>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L, const float *__restrict__ dy,
                                                                    const float *__restrict__ y,
                                                                    const float *__restrict__ x,
                                                                    const float *__restrict__ mean,
                                                                    const float *__restrict__ invstd,
+                                                                   const float *__restrict__ mscale,
+                                                                   const float *__restrict__ mshift,
                                                                    float2 *__restrict__ partial) {
+  constexpr bool RELU = MASK == 1;
   const int c = blockIdx.x % C;
   const float mu = mean[c], is = invstd[c];
+  const float msc = MASK == 2 ? mscale[c] : 0.f, msh = MASK == 2 ? mshift[c] : 0.f;
   const size_t base = (size_t)blockIdx.x * L;
   float s = 0.f, q = 0.f;
   const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (RELU ? (uintptr_t)(y + base) : 0)) % 16 == 0);
@@ -126,12 +132,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L,
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
+    if (MASK == 2) {
+      g.x = fmaf(xv.x, msc, msh) > 0.f ? g.x : 0.f; g.y = fmaf(xv.y, msc, msh) > 0.f ? g.y : 0.f;
+      g.z = fmaf(xv.z, msc, msh) > 0.f ? g.z : 0.f; g.w = fmaf(xv.w, msc, msh) > 0.f ? g.w : 0.f;
+    }
     s += (g.x + g.y) + (g.z + g.w);
     q += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) + (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
   }
   for (int i = (L4 << 2) + threadIdx.x; i < L; i += BN_THREADS) {
     float g = dy[base + i];
     if (RELU) g = y[base + i] > 0.f ? g : 0.f;
+    if (MASK == 2) g = fmaf(x[base + i], msc, msh) > 0.f ? g : 0.f;
     s += g; q += g * ((x[base + i] - mu) * is);
   }
   block_sum2(s, q);
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L,
 }
 
 // dx = k[c] * (g - m1[c] - xhat * m2[c]);  dres = g
-template <bool RELU, bool RES>
+template <int MASK, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, int chunks,
                                                                   const float *__restrict__ dy,
                                                                   const float *__restrict__ y,
@@ -149,18 +160,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
                                                                   const float *__restrict__ kscale,
                                                                   const float *__restrict__ m1,
                                                                   const float *__restrict__ m2,
+                                                                  const float *__restrict__ mscale,
+                                                                  const float *__restrict__ mshift,
                                                                   float *__restrict__ dx,
                                                                   float *__restrict__ dres) {
+  constexpr bool RELU = MASK == 1;
   const int rowi = blockIdx.x / chunks;
   const int chunk = blockIdx.x % chunks;
   const int c = rowi % C;
   const float mu = mean[c], is = invstd[c], kk = kscale[c], a1 = m1[c], a2 = m2[c];
+  const float msc = MASK == 2 ? mscale[c] : 0.f, msh = MASK == 2 ? mshift[c] : 0.f;
   const size_t base = (size_t)rowi * L;
   const int per = (((L + chunks - 1) / chunks) + 3) & ~3;   // multiple of 4: chunk starts stay 16-byte aligned
   const int lo = chunk * per, hi = min(L, lo + per);
   for (int j = lo + threadIdx.x; j < hi; j += BN_THREADS) {
     float g = dy[base + j];
     if (RELU) g = y[base + j] > 0.f ? g : 0.f;
+    if (MASK == 2) g = fmaf(x[base + j], msc, msh) > 0.f ? g : 0.f;
     const float xh = (x[base + j] - mu) * is;
     dx[base + j] = kk * (g - a1 - xh * a2);
     if (RES) dres[base + j] = g;
@@ -200,30 +216,36 @@ extern "C" int p2r_bn_apply(int N, int C, int L, const float *x, const float *sc
 }
 
 extern "C" int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y, const float *x,
-                                 const float *mean, const float *invstd, int relu, float *partial,
-                                 void *stream) {
-  if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
+                                 const float *mean, const float *invstd, int relu, const float *mscale,
+                                 const float *mshift, float *partial, void *stream) {
+  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 2) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   hipStream_t st = p2r_stream(stream);
-  if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, reinterpret_cast<float2 *>(partial));
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, reinterpret_cast<float2 *>(partial));
+  float2 *pp = reinterpret_cast<float2 *>(partial);
+  if (relu == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
+  else if (relu == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
 
 extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y, const float *x,
                                 const float *mean, const float *invstd, const float *kscale,
-                                const float *m1, const float *m2, int relu, float *dx, float *dres,
-                                void *stream) {
-  if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
+                                const float *m1, const float *m2, int relu, const float *mscale,
+                                const float *mshift, float *dx, float *dres, void *stream) {
+  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 2) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   const int rows = N * C, chunks = bn_chunks(rows, L);
   dim3 grid(rows * chunks), blk(BN_THREADS);
   hipStream_t st = p2r_stream(stream);
-  if (relu && dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
-  else if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
-  else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, dx, dres);
+#define P2R_BWA(M, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, R>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, mscale, mshift, dx, dres)
+  if (relu == 1 && dres) P2R_BWA(1, true);
+  else if (relu == 1) P2R_BWA(1, false);
+  else if (relu == 2 && dres) P2R_BWA(2, true);
+  else if (relu == 2) P2R_BWA(2, false);
+  else if (dres) P2R_BWA(0, true);
+  else P2R_BWA(0, false);
+#undef P2R_BWA
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

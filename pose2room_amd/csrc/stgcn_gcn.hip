@@ -342,14 +342,33 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
     const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     __syncthreads();  // previous tile fully consumed (and the table written, first time)
-    for (int c = wave; c < GC_C; c += DW_THREADS / 64) {
-      const float *sx = xg + (size_t)c * row_stride;
-      const float *sd = dg + (size_t)c * row_stride;
-      for (int q = lane; q < DW_F * p.V; q += 64) {
-        const bool in = q < ncols;
-        xs[c * row_len + q] = in ? sx[q] : 0.f;
-        dzs[c * row_len + q] = in ? sd[q] : 0.f;
+    // stage both tiles: all loads of two rows are issued before the first LDS write so the
+    // HBM latency is paid once per row pair, not once per 64-column chunk
+#pragma unroll 1
+    for (int c = wave; c < GC_C; c += 2 * (DW_THREADS / 64)) {
+      float vx[2][4], vd[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float *sx = xg + (size_t)(c + 8 * h) * row_stride;
+        const float *sd = dg + (size_t)(c + 8 * h) * row_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = lane + 64 * i;
+          const bool in = q < ncols;
+          vx[h][i] = in ? sx[q] : 0.f;
+          vd[h][i] = in ? sd[q] : 0.f;
+        }
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = lane + 64 * i;
+          if (q < row_len) {
+            xs[(c + 8 * h) * row_len + q] = vx[h][i];
+            dzs[(c + 8 * h) * row_len + q] = vd[h][i];
+          }
+        }
     }
     __syncthreads();
 
@@ -601,7 +620,7 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   int row_len = DW_F * V;
   while (row_len % 32 != 2) ++row_len;   // row stride == 2 (mod 32): conflict-free column reads
   const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2);
-  if (lds > 160 * 1024) return P2R_EINVAL;
+  if (lds > 160 * 1024 || row_len > 256) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)gcn_dw_kernel,

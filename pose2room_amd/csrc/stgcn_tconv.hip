@@ -1,0 +1,273 @@
+// stgcn_tconv.hip -- temporal (3,1) convolution of st_gcn_block fused with the preceding
+// BatchNorm + ReLU, gfx950.
+//
+// Replaces tcn.0-tcn.2 of the reference's st_gcn_block (models/p2rnet/modules/
+// stgcn_layers.py:399-411): BatchNorm2d -> ReLU -> Conv2d(64, 64, (3,1), padding (1,0)),
+// which run there as a normalisation pass, a ReLU pass and an (NCHW<->NHWC transposed)
+// implicit-GEMM convolution, each a full HBM round trip of the (N,64,T,V) activation.
+//
+// MI355X design: u = sum_dt W_dt . shift_dt(h) is the same "sum over planes of W_k . P_k(X)"
+// shape as the graph convolution (stgcn_gcn.hip) with three planes whose operator is a
+// one-frame shift, so the same MFMA tiling applies: a workgroup stages F+2 frames (one
+// halo frame each side, zero outside the sequence) in LDS -- applying the BatchNorm affine
+// and the ReLU while staging, so the normalised activation never exists in HBM -- and
+// every lane reads its B operand at column offset (dt+1)*V.  v_mfma_f32_16x16x4_f32,
+// 8 waves, A operands (W_dt rows) streamed from L2.  The weight gradient walks the same
+// tiles with the roles of the MFMA dimensions swapped (reduction over columns).
+#include "p2r_common.h"
+
+namespace {
+
+typedef float floatx4c __attribute__((ext_vector_type(4)));
+
+constexpr int TC_C = 64;
+constexpr int TC_NPO = 384;               // output columns per tile (24 n-tiles of 16)
+constexpr int TC_THREADS = 512;
+constexpr int TC_NT = 3;                  // n-tiles per wave
+
+// ---- forward / data-gradient --------------------------------------------------------
+// out[n,c,t,w] = bias[c] + sum_{p<3} sum_ci W[p][c][ci] * h[n,ci,t+p-1,w]
+// h = relu(x*scale+shift) if scale != NULL else x; zero outside [0,T).
+__global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
+    int T, int V, int F, int tiles_per_seq, int row_len, const float *__restrict__ x,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ W,
+    const float *__restrict__ bias, float *__restrict__ out) {
+  extern __shared__ float hs[];   // [64][row_len], frames t0-1 .. t0+F
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  const int seq = blockIdx.x / tiles_per_seq;
+  const int t0 = (blockIdx.x % tiles_per_seq) * F;
+  const int frames = min(F, T - t0);
+  const int ncols = frames * V;
+  const size_t row_stride = (size_t)T * V;
+  const float *xg = x + (size_t)seq * TC_C * row_stride;
+  float *og = out + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+
+  // stage frames t0-1 .. t0+frames (halo), transform on the fly
+  const int in_cols = (frames + 2) * V;
+  const long long col0 = (long long)(t0 - 1) * V;            // may be -V
+  // all loads of a row are issued before its first LDS write (latency paid once per row)
+#pragma unroll 1
+  for (int c = wave; c < TC_C; c += TC_THREADS / 64) {
+    const float *src = xg + (size_t)c * row_stride;
+    const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + 64 * i;
+      const long long gc = col0 + q;
+      const bool in = q < in_cols && gc >= 0 && gc < (long long)row_stride;
+      v[i] = in ? src[in ? gc : 0] : 0.f;
+      if (scale && in) v[i] = fmaxf(fmaf(v[i], sc, sh), 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + 64 * i;
+      if (q < row_len) hs[c * row_len + q] = v[i];
+    }
+  }
+  __syncthreads();
+
+  int colv[TC_NT], base[TC_NT];
+  bool valid[TC_NT];
+#pragma unroll
+  for (int i = 0; i < TC_NT; ++i) {
+    const int col = (wave * TC_NT + i) * 16 + r;
+    colv[i] = col;
+    valid[i] = col < ncols;
+    base[i] = valid[i] ? col : 0;           // input column of plane p: base + p*V
+  }
+  floatx4c acc[TC_NT][4];
+#pragma unroll
+  for (int i = 0; i < TC_NT; ++i)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[i][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
+
+  const float *hg = hs + g * 16 * row_len;
+  for (int p = 0; p < 3; ++p) {
+    float a[4][16];                          // W[p][row 16m + r][ci 16g .. 16g+15]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)p * TC_C + 16 * m + r) * TC_C + 16 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 u = wp[q];
+        a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TC_NT; ++i) {
+      const float *hb = hg + base[i] + p * V;
+      float b[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b[s] = valid[i] ? hb[s * row_len] : 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[i][m], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TC_NT; ++i) {
+    if (!valid[i]) continue;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * m + 4 * g + q;
+        og[(size_t)row * row_stride + colv[i]] = acc[i][m][q] + (bias ? bias[row] : 0.f);
+      }
+  }
+}
+
+// ---- weight gradient ------------------------------------------------------------------
+// dW[p][c][ci] = sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-1,w]   (h as above)
+// persistent grid; wave = (ci tile nt = wave&3, row half mh = wave>>2): 3 planes x 2 row
+// tiles of accumulators; reduction steps of 4 consecutive columns.
+constexpr int TW_F = 4;
+
+__global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
+    int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
+    float *__restrict__ dw_partial) {
+  extern __shared__ float lds[];
+  float *ds = lds;                       // [64][row_d]   dout tile, frames t0 .. t0+F-1
+  float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-1 .. t0+F
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  const int nt = wave & 3, mh = wave >> 2;
+  const int tiles_per_seq = (T + TW_F - 1) / TW_F;
+  const int total_tiles = n_seq * tiles_per_seq;
+  const size_t row_stride = (size_t)T * V;
+
+  floatx4c acc[3][2];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[p][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int seq = tile / tiles_per_seq;
+    const int t0 = (tile % tiles_per_seq) * TW_F;
+    const int frames = min(TW_F, T - t0);
+    const int ncols = frames * V;
+    const float *xg = x + (size_t)seq * TC_C * row_stride;
+    const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+    const long long col0 = (long long)(t0 - 1) * V;
+    __syncthreads();
+#pragma unroll 1
+    for (int c = wave; c < TC_C; c += TC_THREADS / 64) {
+      const float *sx = xg + (size_t)c * row_stride;
+      const float *sd = dg + (size_t)c * row_stride;
+      const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+      float vh[6], vd[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int q = lane + 64 * i;
+        const long long gc = col0 + q;
+        const bool in = q < (frames + 2) * V && gc >= 0 && gc < (long long)row_stride;
+        vh[i] = in ? sx[in ? gc : 0] : 0.f;
+        if (scale && in) vh[i] = fmaxf(fmaf(vh[i], sc, sh), 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        vd[i] = q < ncols ? sd[q] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int q = lane + 64 * i;
+        if (q < row_h) hs[c * row_h + q] = vh[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        if (q < row_d) ds[c * row_d + q] = vd[i];
+      }
+    }
+    __syncthreads();
+
+    const float *drow = ds + (32 * mh + r) * row_d + g;       // + 16*m rows, + 4*s columns
+    const float *hrow = hs + (16 * nt + r) * row_h + g;       // + p*V, + 4*s columns
+    const int steps = (TW_F * V + 3) / 4;
+    for (int s = 0; s < steps; ++s) {
+      const float a0 = drow[4 * s], a1 = drow[16 * row_d + 4 * s];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const float b = hrow[p * V + 4 * s];
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[p][1], 0, 0, 0);
+      }
+    }
+  }
+  // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 32*mh + 16*m + row, ci = 16*nt + r
+  float *outp = dw_partial + (size_t)blockIdx.x * 3 * TC_C * TC_C;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        outp[((size_t)p * TC_C + 32 * mh + 16 * m + 4 * g + q) * TC_C + 16 * nt + r] = acc[p][m][q];
+}
+
+}  // namespace
+
+// x (N,64,T,V); W [3][64][64] (plane p = temporal tap dt = p-1, row = output channel);
+// scale/shift [64] or NULL (input transform relu(x*scale+shift)); bias [64] or NULL.
+extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, const float *scale,
+                                       const float *shift, const float *W, const float *bias, float *out,
+                                       void *stream) {
+  if (N < 0 || T <= 0 || V <= 0 || V > 128) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  int F = TC_NPO / V;
+  if (F < 1) return P2R_EINVAL;
+  if (F > T) F = T;
+  const int tiles_per_seq = p2r_cdiv(T, F);
+  int row_len = (F + 2) * V;
+  if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
+  const size_t lds = (size_t)TC_C * row_len * sizeof(float);
+  if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)tconv_fused_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long long blocks = (long long)N * tiles_per_seq;
+  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+  hipLaunchKernelGGL(tconv_fused_kernel, dim3((unsigned)blocks), dim3(TC_THREADS), lds, p2r_stream(stream), T,
+                     V, F, tiles_per_seq, row_len, x, scale, shift, W, bias, out);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// dw_partial [n_blocks][3][64][64], summed over the leading axis by the caller.
+extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, const float *x, const float *scale,
+                                           const float *shift, const float *dout, int n_blocks,
+                                           float *dw_partial, void *stream) {
+  if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  int row_d = TW_F * V + 3;                      // room for the last (partial) 4-column step
+  while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
+  int row_h = (TW_F + 2) * V + 3;
+  while (row_h % 32 != 2) ++row_h;
+  const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
+  if (lds > 160 * 1024 || row_d > 256 || row_h > 384) return P2R_EINVAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)tconv_dw_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tconv_dw_kernel, dim3(n_blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
+                     row_d, row_h, x, scale, shift, dout, dw_partial);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

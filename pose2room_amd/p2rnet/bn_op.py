@@ -64,7 +64,7 @@ class _FusedBNAct(Function):
         part = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
-                                             _lib.ptr(invstd), int(ctx.relu), _lib.ptr(part),
+                                             _lib.ptr(invstd), int(ctx.relu), None, None, _lib.ptr(part),
                                              _lib.current_stream(dev)), "bn_bwd_reduce")
         tot = part.view(N, C, 2).double().sum(0)
         dbias = tot[:, 0].float()
@@ -78,7 +78,7 @@ class _FusedBNAct(Function):
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(m1), _lib.ptr(m2),
-                                            int(ctx.relu), _lib.ptr(dx), _lib.ptr(dres),
+                                            int(ctx.relu), None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
         return dx, dweight, dbias, dres, None, None, None
 

@@ -159,15 +159,20 @@ class st_gcn_block(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     fused_bn = True   # BatchNorm + residual + ReLU on the fused HIP kernels (GPU tensors)
+    fused_tconv = True   # BatchNorm + ReLU + temporal conv in one kernel
 
     def forward(self, x, A):
         res = self.residual(x)
         x, A = self.gcn(x, A)
         if self.fused_bn and x.is_cuda and self.tcn[4].p == 0:
             from .. import bn_op
+            from .. import tconv_op
             if bn_op.supported(x, self.tcn[0]):
-                h = bn_op.fused_bn_act(x, self.tcn[0], None, relu=True)          # tcn.0 + tcn.1
-                u = self.tcn[2](h)                                                 # temporal (3,1) conv
+                if self.fused_tconv and tconv_op.supported(x, self.tcn[0], self.tcn[2]):
+                    u = tconv_op.bn_relu_tconv(x, self.tcn[0], self.tcn[2])       # tcn.0 + tcn.1 + tcn.2
+                else:
+                    h = bn_op.fused_bn_act(x, self.tcn[0], None, relu=True)      # tcn.0 + tcn.1
+                    u = self.tcn[2](h)                                             # temporal (3,1) conv
                 res_t = res if torch.is_tensor(res) else None
                 return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True), A    # tcn.3 (+res) + relu
         x = self.tcn(x) + res

@@ -1,0 +1,105 @@
+"""BatchNorm -> ReLU -> temporal (3,1) convolution as one fused op (csrc/stgcn_tconv.hip).
+
+`bn_relu_tconv(z, bn, conv)` equals `conv(relu(bn(z)))` for the `tcn.0 / tcn.1 / tcn.2` stage of
+the reference's st_gcn_block (stgcn_layers.py:399-411) with a 64->64 (3,1) conv, stride 1,
+padding (1,0).  The normalised activation is produced while the kernel stages its LDS tile
+and never written to HBM; the backward recomputes the ReLU mask from z.  Differentiable
+w.r.t. z, bn.weight, bn.bias, conv.weight, conv.bias; updates the BatchNorm running
+statistics in training mode like nn.BatchNorm2d.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from . import bn_op
+
+_N_BLOCKS = 256
+
+
+def _tconv(x, scale, shift, W3, bias):
+    N, C, T, V = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().p2r_stgcn_tconv_forward(N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
+                                                      _lib.ptr(W3), _lib.ptr(bias), _lib.ptr(out),
+                                                      _lib.current_stream(x.device)), "stgcn_tconv_forward")
+    return out
+
+
+class _BNReLUTConv(Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, mean, invstd, weight, bias, train):
+        z = z.contiguous()
+        scale = (gamma * invstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        W3 = weight.reshape(64, 64, 3).permute(2, 0, 1).contiguous()            # [tap][c][ci]
+        u = _tconv(z, scale, shift, W3, bias.contiguous() if bias is not None else None)
+        ctx.save_for_backward(z, gamma, mean, invstd, scale, shift, W3)
+        ctx.train = train
+        ctx.has_bias = bias is not None
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        z, gamma, mean, invstd, scale, shift, W3 = ctx.saved_tensors
+        du = du.contiguous()
+        N, C, T, V = z.shape
+        L = T * V
+        dev = z.device
+        lib = _lib.lib()
+        st = _lib.current_stream(dev)
+        # dh[ci, t] = sum_p W[p][c][ci] du[c, t - (p-1)]  ->  same kernel, taps reversed + transposed
+        W3T = W3.flip(0).transpose(1, 2).contiguous()
+        dh = _tconv(du, None, None, W3T, None)
+        dz = dgamma = dbeta = dW = dbias = None
+        with torch.cuda.device(dev):
+            if ctx.train:
+                part = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+                _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
+                                                 _lib.ptr(invstd), 2, _lib.ptr(scale), _lib.ptr(shift),
+                                                 _lib.ptr(part), st), "bn_bwd_reduce")
+                tot = part.view(N, C, 2).double().sum(0)
+                dbeta, dgamma = tot[:, 0].float(), tot[:, 1].float()
+                M = float(N * L)
+                m1 = (tot[:, 0] / M).float().contiguous()
+                m2 = (tot[:, 1] / M).float().contiguous()
+            else:   # eval: statistics are constants, dz = scale * g
+                m1 = torch.zeros(C, device=dev)
+                m2 = torch.zeros(C, device=dev)
+            dz = torch.empty_like(z)
+            _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
+                                            _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
+                                            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
+                       "bn_bwd_apply")
+            part = torch.empty((_N_BLOCKS, 3, 64, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
+                                                       _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), st),
+                       "stgcn_tconv_weight_grad")
+            dW = part.sum(0).permute(1, 2, 0).reshape(64, 64, 3, 1).contiguous()
+            if ctx.has_bias:
+                sp = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+                _lib.check(lib.p2r_bn_stats(N * C, L, _lib.ptr(du), _lib.ptr(sp), st), "bn_stats")
+                dbias = sp.view(N, C, 2)[:, :, 0].double().sum(0).float()
+        return dz, dgamma, dbeta, None, None, dW, dbias, None
+
+
+def supported(z, bn, conv):
+    return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and z.shape[1] == 64 and z.shape[3] <= 64
+            and conv.in_channels == 64 and conv.out_channels == 64 and tuple(conv.kernel_size) == (3, 1)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 0) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and bn_op.supported(z, bn))
+
+
+def bn_relu_tconv(z, bn, conv):
+    if bn.training:
+        mean64, var64, M = bn_op._stats(z.contiguous())
+        with torch.no_grad():
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1 - mom).add_(mom * mean64.float())
+            bn.running_var.mul_(1 - mom).add_(mom * (var64 * (M / max(M - 1.0, 1.0))).float())
+            bn.num_batches_tracked += 1
+        mean = mean64.float()
+        invstd = torch.rsqrt(var64 + bn.eps).float()
+        return _BNReLUTConv.apply(z, bn.weight, bn.bias, mean, invstd, conv.weight, conv.bias, True)
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    return _BNReLUTConv.apply(z, bn.weight, bn.bias, bn.running_mean, invstd, conv.weight, conv.bias, False)
