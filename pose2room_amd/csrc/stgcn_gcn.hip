@@ -121,13 +121,22 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   float *zg = z + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
 
   // ---- stage the X tile (64 rows of `ncols` contiguous floats) and the (nbr, coef) table
-  for (int c = wave; c < GC_C; c += GC_THREADS / 64) {
-    const float *src = xgm + (size_t)c * row_stride;
+#pragma unroll 1
+  for (int c = wave; c < GC_C; c += 4 * (GC_THREADS / 64)) {   // 4 rows in flight per wave
+    float v[4][GC_NP / 64];
 #pragma unroll
-    for (int q0 = 0; q0 < GC_NP; q0 += 64) {
-      const int q = q0 + lane;
-      xs[c * GC_ROW + q] = q < ncols ? src[q] : 0.f;
+    for (int h = 0; h < 4; ++h) {
+      const float *src = xgm + (size_t)(c + 8 * h) * row_stride;
+#pragma unroll
+      for (int i = 0; i < GC_NP / 64; ++i) {
+        const int q = 64 * i + lane;
+        v[h][i] = q < ncols ? src[q] : 0.f;
+      }
     }
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < GC_NP / 64; ++i) xs[(c + 8 * h) * GC_ROW + 64 * i + lane] = v[h][i];
   }
   for (int e = tid; e < ltot * p.V; e += GC_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
@@ -499,13 +508,22 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
     const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     __syncthreads();
-    for (int c = wave; c < GC_C; c += DC_THREADS / 64) {
-      const float *src = xgm + (size_t)c * row_stride;
+#pragma unroll 1
+    for (int c = wave; c < GC_C; c += 4 * (DC_THREADS / 64)) {   // 4 rows in flight per wave
+      float v[4][GC_NP / 64];
 #pragma unroll
-      for (int q0 = 0; q0 < GC_NP; q0 += 64) {
-        const int q = q0 + lane;
-        xs[c * GC_ROW + q] = q < ncols ? src[q] : 0.f;
+      for (int h = 0; h < 4; ++h) {
+        const float *src = xgm + (size_t)(c + 8 * h) * row_stride;
+#pragma unroll
+        for (int i = 0; i < GC_NP / 64; ++i) {
+          const int q = 64 * i + lane;
+          v[h][i] = q < ncols ? src[q] : 0.f;
+        }
       }
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int i = 0; i < GC_NP / 64; ++i) xs[(c + 8 * h) * GC_ROW + 64 * i + lane] = v[h][i];
     }
 
     int fbase[GC_NT16], wj[GC_NT16];
