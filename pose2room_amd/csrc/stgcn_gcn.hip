@@ -450,12 +450,16 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 namespace {
 
 constexpr int DC_THREADS = 512;
+// X tile layout for this kernel: rows interleaved in groups of four, xs4[row >> 2][col] = float4 of
+// rows 4q..4q+3 -- the four accumulator rows a lane holds per 16x16 tile are consecutive, so one
+// ds_read_b128 feeds four FMAs (4x fewer LDS instructions than a row-major tile).
+constexpr int DC_ROW4 = GC_NP + 1;  // float4 elements per row group (odd: spreads the row groups over banks)
 
 // Per-lane partial of dcoef for one (plane, n-tile): sum over this lane's 16 rows of
 // H[row][col] * X[row][(frame, neighbour_j)], for each of the L neighbours; reduced over
 // the four lane groups with LDS float atomics.
 template <int L>
-__device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float *__restrict__ xs, int g,
+__device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float4 *__restrict__ xs4, int g,
                                           const int2 *__restrict__ trow, int V, int fbase,
                                           float *__restrict__ dcs_row) {
   int nb[L];
@@ -465,13 +469,17 @@ __device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float *
 #pragma unroll
   for (int j = 0; j < L; ++j) part[j] = 0.f;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 4; ++m) {
+    const float4 *xr = xs4 + (4 * m + g) * DC_ROW4 + fbase;     // rows 16m + 4g .. +3
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float *xr = xs + (16 * m + 4 * g + q) * GC_ROW + fbase;
-#pragma unroll
-      for (int j = 0; j < L; ++j) part[j] = fmaf(h[m][q], xr[nb[j]], part[j]);
+    for (int j = 0; j < L; ++j) {
+      const float4 xv = xr[nb[j]];
+      part[j] = fmaf(h[m][0], xv.x, part[j]);
+      part[j] = fmaf(h[m][1], xv.y, part[j]);
+      part[j] = fmaf(h[m][2], xv.z, part[j]);
+      part[j] = fmaf(h[m][3], xv.w, part[j]);
     }
+  }
 #pragma unroll
   for (int j = 0; j < L; ++j) atomicAdd(dcs_row + j * V, part[j]);
 }
@@ -483,8 +491,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
                                                                   const uint8_t *__restrict__ nbr,
                                                                   float *__restrict__ dcoef_partial) {
   extern __shared__ float lds[];
-  float *xs = lds;                                                   // [64][GC_ROW]
-  int2 *tbl = reinterpret_cast<int2 *>(lds + GC_C * GC_ROW);         // [ltot][V] (nbr, unused)
+  float4 *xs4 = reinterpret_cast<float4 *>(lds);                     // [16 row groups][DC_ROW4] float4
+  int2 *tbl = reinterpret_cast<int2 *>(lds + 16 * DC_ROW4 * 4);      // [ltot][V] (nbr, unused)
   float *dcs = reinterpret_cast<float *>(tbl + ltot * p.V);          // [ltot][V]
 
   const int tid = threadIdx.x;
@@ -509,11 +517,11 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     __syncthreads();
 #pragma unroll 1
-    for (int c = wave; c < GC_C; c += 4 * (DC_THREADS / 64)) {   // 4 rows in flight per wave
+    for (int rg = wave; rg < GC_C / 4; rg += DC_THREADS / 64) {       // row group = 4 consecutive rows
       float v[4][GC_NP / 64];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        const float *src = xgm + (size_t)(c + 8 * h) * row_stride;
+        const float *src = xgm + (size_t)(4 * rg + h) * row_stride;
 #pragma unroll
         for (int i = 0; i < GC_NP / 64; ++i) {
           const int q = 64 * i + lane;
@@ -521,9 +529,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         }
       }
 #pragma unroll
-      for (int h = 0; h < 4; ++h)
-#pragma unroll
-        for (int i = 0; i < GC_NP / 64; ++i) xs[(c + 8 * h) * GC_ROW + 64 * i + lane] = v[h][i];
+      for (int i = 0; i < GC_NP / 64; ++i)
+        xs4[rg * DC_ROW4 + 64 * i + lane] = make_float4(v[0][i], v[1][i], v[2][i], v[3][i]);
     }
 
     int fbase[GC_NT16], wj[GC_NT16];
@@ -570,18 +577,18 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
           const int2 *trow = tbl + lofs * p.V + wj[i];
           float *drow = dcs + lofs * p.V + wj[i];
           switch (L) {
-            case 1: dc_reduce<1>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 2: dc_reduce<2>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 3: dc_reduce<3>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 4: dc_reduce<4>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 5: dc_reduce<5>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 6: dc_reduce<6>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 7: dc_reduce<7>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 8: dc_reduce<8>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 9: dc_reduce<9>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 10: dc_reduce<10>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            case 11: dc_reduce<11>(h, xs, g, trow, p.V, fbase[i], drow); break;
-            default: dc_reduce<12>(h, xs, g, trow, p.V, fbase[i], drow); break;
+            case 1: dc_reduce<1>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 2: dc_reduce<2>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 3: dc_reduce<3>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 4: dc_reduce<4>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 5: dc_reduce<5>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 6: dc_reduce<6>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 7: dc_reduce<7>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 8: dc_reduce<8>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 9: dc_reduce<9>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 10: dc_reduce<10>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            case 11: dc_reduce<11>(h, xs4, g, trow, p.V, fbase[i], drow); break;
+            default: dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow); break;
           }
         }
       }
@@ -662,7 +669,7 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
   if (ltot < 0) return ltot;
   if (N < 0 || n_blocks < 1) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  const size_t lds = (size_t)GC_C * GC_ROW * sizeof(float) + (size_t)ltot * V * (sizeof(int2) + sizeof(float));
+  const size_t lds = (size_t)16 * DC_ROW4 * sizeof(float4) + (size_t)ltot * V * (sizeof(int2) + sizeof(float));
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {

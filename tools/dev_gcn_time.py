@@ -25,3 +25,11 @@ e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 e[0].record(); z = gcn_op.graph_conv(x, w, b, At * imp, tables); e[1].record(); z.backward(go); e[2].record(); e[2].synchronize()
 fl = 2 * 64 * K * 64 * N * T * V
 print(f'fwd {e[0].elapsed_time(e[1]):.3f} ms ({fl / e[0].elapsed_time(e[1]) / 1e9:.1f} TF dense)  bwd {e[1].elapsed_time(e[2]):.3f} ms')
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(4):
+        z = gcn_op.graph_conv(x, w, b, At * imp, tables)
+        z.backward(go)
+    torch.cuda.synchronize()
+for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:4]:
+    print(f'{e.key[:48]:48s} n={e.count:3d} avg {e.device_time_total / e.count / 1e3:.3f} ms')
