@@ -47,54 +47,58 @@ struct GcnParams {
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GC_ROW = GC_NP + 1;   // odd LDS row stride: the two 16-lane groups of a half-wave
-                                    // (rows 16 apart) land on bank sets shifted by 16
+constexpr int GC_ROW = GC_NP + 1;   // (kept for sizing) row-major stride of earlier versions
+constexpr int GC_ROW4 = GC_NP + 1;  // float4 elements per group of four rows (X tile is row-interleaved)
 constexpr int GC_THREADS = 512;     // 8 waves: two per SIMD, so one wave's LDS / L2 waits hide
                                     // under the other's MFMAs
 constexpr int GC_NT16 = 3;          // 16-column n-tiles per wave (8 waves x 3 x 16 = 384 columns)
 
 // One (plane, n-tile) unit with v_mfma_f32_16x16x4_f32: 16 k-steps; lane (g = lane>>4,
 // r = lane&15) builds B[k = g][col = r] = (X . A_k)[channel 16g + s][column] from L
-// gathered LDS values and feeds the four 16-row output tiles.  Gathers of step s+2/s+3
-// are issued before the FMAs / MFMAs of steps s/s+1.
+// gathered LDS values and feeds the four 16-row output tiles.  The X tile is stored with
+// rows interleaved in groups of four (float4 per (row group, column)), so one ds_read_b128
+// serves four consecutive k-steps; gathers of the next chunk are issued before the FMAs /
+// MFMAs of the current one.  Long neighbour lists are processed in two halves to bound the
+// number of live gather registers.
 template <int L>
-__device__ __forceinline__ void agg_mfma16(const float *__restrict__ xg, const int (&off)[GC_MAXL],
+__device__ __forceinline__ void agg_mfma16(const float4 *__restrict__ xg4, const int (&off)[GC_MAXL],
                                            const float (&cf)[GC_MAXL], const float (&a)[4][16],
                                            floatx4_t (&acc)[4]) {
-  float xc[2][L], xn[2][L];
+  constexpr int H = L > 6 ? 2 : 1;            // list halves
+  constexpr int LC = (L + H - 1) / H;         // entries per half
+  float4 xc[LC], xn[LC];
 #pragma unroll
-  for (int j = 0; j < L; ++j) {
-    xc[0][j] = xg[off[j]];
-    xc[1][j] = xg[GC_ROW + off[j]];
-  }
+  for (int j = 0; j < LC; ++j) xc[j] = xg4[off[j]];
+  float b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int pr = 0; pr < 8; ++pr) {
-    if (pr + 1 < 8) {
+  for (int ch = 0; ch < 4 * H; ++ch) {        // chunk = (row quad qd, list half hf)
+    const int qd = ch / H, hf = ch % H;
+    if (ch + 1 < 4 * H) {
+      const int nqd = (ch + 1) / H, nhf = (ch + 1) % H;
 #pragma unroll
-      for (int j = 0; j < L; ++j) {
-        xn[0][j] = xg[(2 * pr + 2) * GC_ROW + off[j]];
-        xn[1][j] = xg[(2 * pr + 3) * GC_ROW + off[j]];
+      for (int j = 0; j < LC; ++j)
+        if (nhf * LC + j < L) xn[j] = xg4[nqd * GC_ROW4 + off[nhf * LC + j]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < LC; ++j)
+      if (hf * LC + j < L) {
+        const float c = cf[hf * LC + j];
+        b[0] = fmaf(c, xc[j].x, b[0]); b[1] = fmaf(c, xc[j].y, b[1]);
+        b[2] = fmaf(c, xc[j].z, b[2]); b[3] = fmaf(c, xc[j].w, b[3]);
       }
+    if (hf == H - 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][4 * qd + t], b[t], acc[m], 0, 0, 0);
+      }
+      b[0] = b[1] = b[2] = b[3] = 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
-    float b0 = 0.f, b1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-      b0 = fmaf(cf[j], xc[0][j], b0);
-      b1 = fmaf(cf[j], xc[1][j], b1);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][2 * pr], b0, acc[m], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][2 * pr + 1], b1, acc[m], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      xc[0][j] = xn[0][j];
-      xc[1][j] = xn[1][j];
-    }
+    for (int j = 0; j < LC; ++j) xc[j] = xn[j];
   }
 }
 
@@ -102,8 +106,9 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
     GcnParams p, int ltot, const float *__restrict__ x, const float *__restrict__ W,
     const uint8_t *__restrict__ nbr, const float *__restrict__ coef,
     const float *__restrict__ bias_cv, float *__restrict__ z) {
-  extern __shared__ float xs[];                       // [GC_C][GC_ROW] floats, then the int2 table
-  int2 *tbl = reinterpret_cast<int2 *>(xs + GC_C * GC_ROW);   // GC_C*GC_ROW floats = 8-byte multiple
+  extern __shared__ float xs[];                       // [16 row groups][GC_ROW4] float4, then the int2 table
+  float4 *xs4 = reinterpret_cast<float4 *>(xs);
+  int2 *tbl = reinterpret_cast<int2 *>(xs + 16 * GC_ROW4 * 4);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -122,11 +127,11 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
 
   // ---- stage the X tile (64 rows of `ncols` contiguous floats) and the (nbr, coef) table
 #pragma unroll 1
-  for (int c = wave; c < GC_C; c += 4 * (GC_THREADS / 64)) {   // 4 rows in flight per wave
+  for (int rg = wave; rg < GC_C / 4; rg += GC_THREADS / 64) {   // row group = 4 consecutive rows
     float v[4][GC_NP / 64];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const float *src = xgm + (size_t)(c + 8 * h) * row_stride;
+      const float *src = xgm + (size_t)(4 * rg + h) * row_stride;
 #pragma unroll
       for (int i = 0; i < GC_NP / 64; ++i) {
         const int q = 64 * i + lane;
@@ -134,9 +139,8 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
       }
     }
 #pragma unroll
-    for (int h = 0; h < 4; ++h)
-#pragma unroll
-      for (int i = 0; i < GC_NP / 64; ++i) xs[(c + 8 * h) * GC_ROW + 64 * i + lane] = v[h][i];
+    for (int i = 0; i < GC_NP / 64; ++i)
+      xs4[rg * GC_ROW4 + 64 * i + lane] = make_float4(v[0][i], v[1][i], v[2][i], v[3][i]);
   }
   for (int e = tid; e < ltot * p.V; e += GC_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[i][m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
-  const float *xg = xs + g * 16 * GC_ROW;   // this lane group's 16 input channels
+  const float4 *xg = xs4 + 4 * g * GC_ROW4;   // this lane group's 16 input channels = 4 row groups
 
   for (int k = 0; k < p.K; ++k) {
     // A operands: W_k[row 16m + r][channels 16g .. 16g+15]
@@ -244,7 +248,7 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
   }
   const long long blocks = (long long)N * p.tiles_per_seq;
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
-  const size_t lds = ((size_t)GC_C * GC_ROW + 2) * sizeof(float) + (size_t)ofs * V * sizeof(int2);
+  const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2);
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
