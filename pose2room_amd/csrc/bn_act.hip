@@ -173,13 +173,35 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
   const size_t base = (size_t)rowi * L;
   const int per = (((L + chunks - 1) / chunks) + 3) & ~3;   // multiple of 4: chunk starts stay 16-byte aligned
   const int lo = chunk * per, hi = min(L, lo + per);
-  for (int j = lo + threadIdx.x; j < hi; j += BN_THREADS) {
-    float g = dy[base + j];
-    if (RELU) g = y[base + j] > 0.f ? g : 0.f;
-    if (MASK == 2) g = fmaf(x[base + j], msc, msh) > 0.f ? g : 0.f;
-    const float xh = (x[base + j] - mu) * is;
-    dx[base + j] = kk * (g - a1 - xh * a2);
-    if (RES) dres[base + j] = g;
+  auto one = [&](float g, float yv, float xv, float &dxo, float &dro) {
+    if (RELU) g = yv > 0.f ? g : 0.f;
+    if (MASK == 2) g = fmaf(xv, msc, msh) > 0.f ? g : 0.f;
+    const float xh = (xv - mu) * is;
+    dxo = kk * (g - a1 - xh * a2);
+    dro = g;
+  };
+  const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (uintptr_t)(dx + base) |
+                     (RELU ? (uintptr_t)(y + base) : 0) | (RES ? (uintptr_t)(dres + base) : 0)) % 16 == 0);
+  int tail = lo;
+  if (vec) {
+    tail = lo + ((hi - lo) & ~3);
+    for (int j = lo + threadIdx.x * 4; j + 3 < hi; j += BN_THREADS * 4) {
+      const float4 g4 = *reinterpret_cast<const float4 *>(dy + base + j);
+      const float4 x4 = *reinterpret_cast<const float4 *>(x + base + j);
+      float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RELU) y4 = *reinterpret_cast<const float4 *>(y + base + j);
+      float4 o, rr;
+      one(g4.x, y4.x, x4.x, o.x, rr.x); one(g4.y, y4.y, x4.y, o.y, rr.y);
+      one(g4.z, y4.z, x4.z, o.z, rr.z); one(g4.w, y4.w, x4.w, o.w, rr.w);
+      *reinterpret_cast<float4 *>(dx + base + j) = o;
+      if (RES) *reinterpret_cast<float4 *>(dres + base + j) = rr;
+    }
+  }
+  for (int j = tail + threadIdx.x; j < hi; j += BN_THREADS) {
+    float o, rr;
+    one(dy[base + j], RELU ? y[base + j] : 0.f, x[base + j], o, rr);
+    dx[base + j] = o;
+    if (RES) dres[base + j] = rr;
   }
 }
 

@@ -69,6 +69,19 @@ class STGCN(nn.Module):
             return torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)
         raise NotImplementedError
 
+    @staticmethod
+    def _mlp(seq, x):
+        """Run a `_point_mlp` stack; on the GPU each conv+BatchNorm+ReLU stage uses the fused
+        BatchNorm/ReLU kernels instead of separate normalisation and activation passes."""
+        from .. import bn_op
+        for stage in seq:
+            if x.is_cuda and hasattr(stage, 'batchnorm') and hasattr(stage, 'ReLU') and \
+                    bn_op.supported(x, stage.batchnorm):
+                x = bn_op.fused_bn_act(stage.conv(x), stage.batchnorm, None, relu=True)
+            else:
+                x = stage(x)
+        return x
+
     def embed(self, input_joints):
         """(B,T,J,3) -> (B,64,T,J): joint embedding + temporal-window position embedding
         (stgcn.py:105-130).  The reference builds the same tensor through
@@ -80,10 +93,10 @@ class STGCN(nn.Module):
             torch.arange(-self.knn // 2, self.knn // 2, device=device).unsqueeze(0)
         win = win.clamp_(0, n_frames - 1)                                      # (T,knn)
         offs = hip[:, win] - hip.unsqueeze(2)                                  # (B,T,knn,3)
-        pe = self.pos_embed(offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2))
+        pe = self._mlp(self.pos_embed, offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2))
         pe = pe.view(n_batch, -1, n_frames, self.knn).mean(dim=3)             # (B,64,T)
         rel = input_joints - input_joints[:, :, [self.origin_joint_id]]
-        sk = self.sk_feat(rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2))
+        sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2))
         return sk.view(n_batch, -1, n_frames, n_joints) + pe.unsqueeze(-1)
 
     def forward(self, input_joints, end_points=None):
