@@ -28,98 +28,121 @@ constexpr int TC_NT = 3;                  // n-tiles per wave
 // ---- forward / data-gradient --------------------------------------------------------
 // out[n,c,t,w] = bias[c] + sum_{p<3} sum_ci W[p][c][ci] * h[n,ci,t+p-1,w]
 // h = relu(x*scale+shift) if scale != NULL else x; zero outside [0,T).
+// Persistent: each workgroup walks tiles blockIdx.x, +gridDim.x, ...; the global loads of the
+// NEXT tile are issued into registers before the MFMA phase of the current one, so HBM latency
+// and transfer hide under compute even though only one workgroup fits a CU (LDS).
 __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
-    int T, int V, int F, int tiles_per_seq, int row_len, const float *__restrict__ x,
+    int n_seq, int T, int V, int F, int tiles_per_seq, int row_len, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out) {
   extern __shared__ float hs[];   // [64][row_len], frames t0-1 .. t0+F
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
-  const int seq = blockIdx.x / tiles_per_seq;
-  const int t0 = (blockIdx.x % tiles_per_seq) * F;
-  const int frames = min(F, T - t0);
-  const int ncols = frames * V;
   const size_t row_stride = (size_t)T * V;
-  const float *xg = x + (size_t)seq * TC_C * row_stride;
-  float *og = out + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+  const int total_tiles = n_seq * tiles_per_seq;
 
-  // stage frames t0-1 .. t0+frames (halo), transform on the fly
-  const int in_cols = (frames + 2) * V;
-  const long long col0 = (long long)(t0 - 1) * V;            // may be -V
-  // all loads of a row are issued before its first LDS write (latency paid once per row)
-#pragma unroll 1
-  for (int c = wave; c < TC_C; c += TC_THREADS / 64) {
-    const float *src = xg + (size_t)c * row_stride;
-    const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
-    float v[8];
+  float pre[8][8];                 // this lane's share of a tile: 8 rows (wave, wave+8, ..) x 8 chunks
+  auto issue_loads = [&](int tile) {
+    const int seq = tile / tiles_per_seq;
+    const int t0 = (tile % tiles_per_seq) * F;
+    const int frames = min(F, T - t0);
+    const int in_cols = (frames + 2) * V;
+    const long long col0 = (long long)(t0 - 1) * V;
+    const float *xg = x + (size_t)seq * TC_C * row_stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int q = lane + 64 * i;
-      const long long gc = col0 + q;
-      const bool in = q < in_cols && gc >= 0 && gc < (long long)row_stride;
-      v[i] = in ? src[in ? gc : 0] : 0.f;
-      if (scale && in) v[i] = fmaxf(fmaf(v[i], sc, sh), 0.f);
-    }
+    for (int h = 0; h < 8; ++h) {
+      const float *src = xg + (size_t)(wave + 8 * h) * row_stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int q = lane + 64 * i;
-      if (q < row_len) hs[c * row_len + q] = v[i];
-    }
-  }
-  __syncthreads();
-
-  int colv[TC_NT], base[TC_NT];
-  bool valid[TC_NT];
-#pragma unroll
-  for (int i = 0; i < TC_NT; ++i) {
-    const int col = (wave * TC_NT + i) * 16 + r;
-    colv[i] = col;
-    valid[i] = col < ncols;
-    base[i] = valid[i] ? col : 0;           // input column of plane p: base + p*V
-  }
-  floatx4c acc[TC_NT][4];
-#pragma unroll
-  for (int i = 0; i < TC_NT; ++i)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[i][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
-
-  const float *hg = hs + g * 16 * row_len;
-  for (int p = 0; p < 3; ++p) {
-    float a[4][16];                          // W[p][row 16m + r][ci 16g .. 16g+15]
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)p * TC_C + 16 * m + r) * TC_C + 16 * g);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 u = wp[q];
-        a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
+      for (int i = 0; i < 8; ++i) {
+        const int q = lane + 64 * i;
+        const long long gc = col0 + q;
+        const bool in = q < in_cols && gc >= 0 && gc < (long long)row_stride;
+        pre[h][i] = in ? src[in ? gc : 0] : __int_as_float(0x7fc00000);   // NaN marks "outside": stays zero
       }
     }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue_loads(tile);
+  for (; tile < total_tiles; tile += gridDim.x) {
+    const int seq = tile / tiles_per_seq;
+    const int t0 = (tile % tiles_per_seq) * F;
+    const int frames = min(F, T - t0);
+    const int ncols = frames * V;
+    float *og = out + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+
+    // registers -> LDS with the BatchNorm affine + ReLU applied on the way
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const int c = wave + 8 * h;
+      const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lane + 64 * i;
+        float v = pre[h][i];
+        if (v != v) v = 0.f;                                   // outside the sequence / tile
+        else if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (q < row_len) hs[c * row_len + q] = v;
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
+
+    int colv[TC_NT], base[TC_NT];
+    bool valid[TC_NT];
 #pragma unroll
     for (int i = 0; i < TC_NT; ++i) {
-      const float *hb = hg + base[i] + p * V;
-      float b[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) b[s] = valid[i] ? hb[s * row_len] : 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[i][m], 0, 0, 0);
+      const int col = (wave * TC_NT + i) * 16 + r;
+      colv[i] = col;
+      valid[i] = col < ncols;
+      base[i] = valid[i] ? col : 0;           // input column of plane p: base + p*V
     }
-  }
+    floatx4c acc[TC_NT][4];
+#pragma unroll
+    for (int i = 0; i < TC_NT; ++i)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[i][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
+
+    const float *hg = hs + g * 16 * row_len;
+    for (int ph = 0; ph < 6; ++ph) {           // (tap p, half of the 16 k-steps): keeps A operands at 32 VGPRs
+      const int p = ph >> 1, hf = ph & 1;
+      float a[4][8];                           // W[p][row 16m + r][ci 16g + 8hf .. +8)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 *wp = reinterpret_cast<const float4 *>(W + ((size_t)p * TC_C + 16 * m + r) * TC_C + 16 * g + 8 * hf);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 u = wp[q];
+          a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TC_NT; ++i) {
+        const float *hb = hg + base[i] + p * V + 8 * hf * row_len;
+        float b[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) b[s2] = valid[i] ? hb[s2 * row_len] : 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s2], b[s2], acc[i][m], 0, 0, 0);
+      }
+    }
 
 #pragma unroll
-  for (int i = 0; i < TC_NT; ++i) {
-    if (!valid[i]) continue;
+    for (int i = 0; i < TC_NT; ++i) {
+      if (!valid[i]) continue;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = 16 * m + 4 * g + q;
-        og[(size_t)row * row_stride + colv[i]] = acc[i][m][q] + (bias ? bias[row] : 0.f);
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * m + 4 * g + q;
+          og[(size_t)row * row_stride + colv[i]] = acc[i][m][q] + (bias ? bias[row] : 0.f);
+        }
+    }
+    __syncthreads();   // every wave is done with the LDS tile before it is overwritten
   }
 }
 
@@ -239,10 +262,11 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, cons
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const long long blocks = (long long)N * tiles_per_seq;
-  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
-  hipLaunchKernelGGL(tconv_fused_kernel, dim3((unsigned)blocks), dim3(TC_THREADS), lds, p2r_stream(stream), T,
-                     V, F, tiles_per_seq, row_len, x, scale, shift, W, bias, out);
+  const long long tiles = (long long)N * tiles_per_seq;
+  if (tiles > 0x7fffffffLL) return P2R_EINVAL;
+  const int blocks = (int)(tiles < 256 ? tiles : 256);      // persistent: one workgroup per CU
+  hipLaunchKernelGGL(tconv_fused_kernel, dim3(blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V, F,
+                     tiles_per_seq, row_len, x, scale, shift, W, bias, out);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

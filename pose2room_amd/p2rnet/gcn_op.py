@@ -19,6 +19,8 @@ from .. import _lib
 from . import gcn_tables
 
 _N_BLOCKS = 256     # persistent workgroups of the reduction kernels (one per CU)
+_MERGED_BWD = False  # dX and dcoef from one dense pass (gcn_bwd_data_coef_kernel): correct, but at 4.6 ms vs
+                     # 1.9 + 2.6 ms for the two separate kernels not yet a win -- kept for the next round
 
 
 class GraphTables:
@@ -74,8 +76,20 @@ class _GraphConv(Function):
         K = tables.K
         Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
         dx = dW = dcoef = dbias = None
-        if ctx.needs_input_grad[0]:
-            # dX = sum_k W_k^T (dZ . A_k^T): same kernel, transposed planes + row lists
+        merged = ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and 4 * V <= 256 and _MERGED_BWD
+        if merged:
+            # one dense pass for both dX and the adjacency gradient (csrc: gcn_bwd_data_coef_kernel)
+            ltot = coef_c.shape[0]
+            dx = torch.empty_like(x)
+            part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().p2r_stgcn_gcn_data_coef_grad(
+                    N, T, V, K, tables.LkA_c, tables.LkA_r, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wt),
+                    _lib.ptr(t['nbr_c']), _lib.ptr(t['nbr_r']), _lib.ptr(coef_r.contiguous()), _N_BLOCKS,
+                    _lib.ptr(dx), _lib.ptr(part), _lib.current_stream(dev)), "stgcn_gcn_data_coef_grad")
+            dcoef = part.sum(0)
+        elif ctx.needs_input_grad[0]:
+            # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
             dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
         st = _lib.current_stream(dev)
@@ -86,7 +100,7 @@ class _GraphConv(Function):
                     N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(t['nbr_c']),
                     _lib.ptr(coef_c.contiguous()), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_weight_grad")
                 dW = part.sum(0).view(K * C, C)
-            if ctx.needs_input_grad[2]:
+            if ctx.needs_input_grad[2] and not merged:
                 ltot = coef_c.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_stgcn_gcn_coef_grad(
