@@ -293,12 +293,17 @@ struct DwSets {                   // host-balanced split of the planes over the 
 };
 
 // b[f] += sum_j coef * X[ci row][frame f, joint nbr_j]  for one plane; L compile-time.
+// L = compile-time list capacity (a few sizes only, to bound code size), Lr = real length.
 template <int L>
 __device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstride,
-                                         const float *__restrict__ xrow, int V, bool live, float (&b)[DW_F]) {
+                                         const float *__restrict__ xrow, int V, bool live, int Lr,
+                                         float (&b)[DW_F]) {
   int2 e[L];
 #pragma unroll
-  for (int j = 0; j < L; ++j) e[j] = trow[j * tstride];
+  for (int j = 0; j < L; ++j) {
+    e[j] = trow[(j < Lr ? j : 0) * tstride];
+    if (j >= Lr) e[j].y = 0;                     // coefficient 0 for the padding slots
+  }
   float xv[L][DW_F];
 #pragma unroll
   for (int j = 0; j < L; ++j)
@@ -343,10 +348,16 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
   const int n_groups = (p.V + 3) / 4;
 
   floatx4 acc[DW_PL][4];
+  int pl_k[DW_PL], pl_L[DW_PL], pl_row[DW_PL];   // this wave's planes, hoisted out of the loops (SGPRs)
 #pragma unroll
-  for (int kk = 0; kk < DW_PL; ++kk)
+  for (int kk = 0; kk < DW_PL; ++kk) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[kk][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int k = sets.plane[half][kk];
+    pl_k[kk] = k;
+    pl_L[kk] = k >= 0 ? p.Lk[k] : 0;
+    pl_row[kk] = k >= 0 ? p.Lofs[k] * p.V : 0;
+  }
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int seq = tile / tiles_per_seq;
@@ -398,24 +409,15 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
         for (int f = 0; f < DW_F; ++f) a[m][f] = live ? drow[16 * m * row_len + f * p.V + wc] : 0.f;
 #pragma unroll
       for (int kk = 0; kk < DW_PL; ++kk) {
-        const int k = sets.plane[half][kk];
-        if (k < 0) continue;                             // uniform
+        if (pl_k[kk] < 0) continue;                      // uniform
         float b[DW_F];
-        const int2 *trow = tbl + p.Lofs[k] * p.V + wc;
-        switch (p.Lk[k]) {
-          case 1: dw_plane<1>(trow, p.V, xrow, p.V, live, b); break;
-          case 2: dw_plane<2>(trow, p.V, xrow, p.V, live, b); break;
-          case 3: dw_plane<3>(trow, p.V, xrow, p.V, live, b); break;
-          case 4: dw_plane<4>(trow, p.V, xrow, p.V, live, b); break;
-          case 5: dw_plane<5>(trow, p.V, xrow, p.V, live, b); break;
-          case 6: dw_plane<6>(trow, p.V, xrow, p.V, live, b); break;
-          case 7: dw_plane<7>(trow, p.V, xrow, p.V, live, b); break;
-          case 8: dw_plane<8>(trow, p.V, xrow, p.V, live, b); break;
-          case 9: dw_plane<9>(trow, p.V, xrow, p.V, live, b); break;
-          case 10: dw_plane<10>(trow, p.V, xrow, p.V, live, b); break;
-          case 11: dw_plane<11>(trow, p.V, xrow, p.V, live, b); break;
-          default: dw_plane<12>(trow, p.V, xrow, p.V, live, b); break;
-        }
+        const int2 *trow = tbl + pl_row[kk] + wc;
+        const int Lr = pl_L[kk];
+        if (Lr <= 1) dw_plane<1>(trow, p.V, xrow, p.V, live, Lr, b);
+        else if (Lr <= 3) dw_plane<3>(trow, p.V, xrow, p.V, live, Lr, b);
+        else if (Lr <= 5) dw_plane<5>(trow, p.V, xrow, p.V, live, Lr, b);
+        else if (Lr <= 8) dw_plane<8>(trow, p.V, xrow, p.V, live, Lr, b);
+        else dw_plane<12>(trow, p.V, xrow, p.V, live, Lr, b);
 #pragma unroll
         for (int f = 0; f < DW_F; ++f)
 #pragma unroll
@@ -465,10 +467,10 @@ constexpr int DC_ROW4 = GC_NP + 1;  // float4 elements per row group (odd: sprea
 template <int L>
 __device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float4 *__restrict__ xs4, int g,
                                           const int2 *__restrict__ trow, int V, int fbase,
-                                          float *__restrict__ dcs_row) {
+                                          float *__restrict__ dcs_row, int Lr) {
   int nb[L];
 #pragma unroll
-  for (int j = 0; j < L; ++j) nb[j] = trow[j * V].x;
+  for (int j = 0; j < L; ++j) nb[j] = trow[(j < Lr ? j : 0) * V].x;   // L = capacity, Lr = real length
   float part[L];
 #pragma unroll
   for (int j = 0; j < L; ++j) part[j] = 0.f;
@@ -485,7 +487,8 @@ __device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float4 
     }
   }
 #pragma unroll
-  for (int j = 0; j < L; ++j) atomicAdd(dcs_row + j * V, part[j]);
+  for (int j = 0; j < L; ++j)
+    if (j < Lr) atomicAdd(dcs_row + j * V, part[j]);
 }
 
 __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
@@ -580,20 +583,11 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         if (valid[i]) {
           const int2 *trow = tbl + lofs * p.V + wj[i];
           float *drow = dcs + lofs * p.V + wj[i];
-          switch (L) {
-            case 1: dc_reduce<1>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 2: dc_reduce<2>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 3: dc_reduce<3>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 4: dc_reduce<4>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 5: dc_reduce<5>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 6: dc_reduce<6>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 7: dc_reduce<7>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 8: dc_reduce<8>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 9: dc_reduce<9>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 10: dc_reduce<10>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            case 11: dc_reduce<11>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-            default: dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow); break;
-          }
+          if (L <= 1) dc_reduce<1>(h, xs4, g, trow, p.V, fbase[i], drow, L);
+          else if (L <= 3) dc_reduce<3>(h, xs4, g, trow, p.V, fbase[i], drow, L);
+          else if (L <= 5) dc_reduce<5>(h, xs4, g, trow, p.V, fbase[i], drow, L);
+          else if (L <= 8) dc_reduce<8>(h, xs4, g, trow, p.V, fbase[i], drow, L);
+          else dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow, L);
         }
       }
     }

@@ -1,0 +1,29 @@
+import os, sys, ctypes, glob
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+from pose2room_amd.p2rnet import gcn_tables
+dev = torch.device('cuda:0')
+A = Graph().A
+N, T, V, K = 32, 1024, 53, 11
+nbr, gidx, Lk = gcn_tables.build(A)
+x = torch.randn(N, 64, T, V, device=dev); dz = torch.randn(N, 64, T, V, device=dev)
+coef = gcn_tables.coefficients(torch.tensor(A, dtype=torch.float32, device=dev), gidx.to(dev)).contiguous()
+nb = nbr.to(dev)
+part = torch.empty(256, K, 64, 64, device=dev)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'))):
+    lib = ctypes.CDLL(so)
+    LkA = (ctypes.c_int * K)(*Lk)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    def call():
+        assert lib.p2r_stgcn_gcn_weight_grad(N, T, V, K, LkA, p(x), p(dz), p(nb), p(coef), 256, p(part), st) == 0
+    for _ in range(2): call()
+    ts = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): call()
+        e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 5)
+    print(os.path.basename(so), ' '.join(f'{t:.3f}' for t in ts), 'ms')
