@@ -179,3 +179,53 @@ def assembly_gt_map_cls(parsed_gts, mesh_outputs=None, voxel_size=0.047):
     mask = parsed_gts['box_label_mask']
     return [[(sem_cls_label[i, j].item(), corners[i, j]) for j in range(corners.shape[1]) if mask[i, j] == 1]
             for i in range(sem_cls_label.shape[0])]
+
+
+class APCalculator(object):
+    """Accumulates per-scan predictions / ground truths and computes AP, mAP, recall and AR
+    (net_utils/ap_helper.py:24-128, mesh-free branch; the class P2RNet's test loop instantiates with
+    `evaluate_mesh=False`, test_epoch.py:22).  Same constructor, `step`, `compute_metrics`, `reset`
+    and result keys ('<cls> Average Precision', 'mAP', '<cls> Recall', 'AR')."""
+
+    def __init__(self, ap_iou_thresh=0.25, class2type_map=None, evaluate_mesh=False, device='cpu'):
+        if evaluate_mesh:
+            raise NotImplementedError("mesh AP (voxelised-mesh IoU, ap_helper.py:86-128) is outside the P2RNet path")
+        self.ap_iou_thresh = ap_iou_thresh
+        self.class2type_map = class2type_map
+        self.evaluate_mesh = evaluate_mesh
+        self.device = device
+        self.reset()
+
+    def step(self, batch_pred_map_cls, batch_gt_map_cls):
+        """batch_pred_map_cls [[(cls, corners (8,3), score), ...], ...]; batch_gt_map_cls [[(cls, corners), ...], ...]."""
+        bsize = len(batch_pred_map_cls)
+        assert bsize == len(batch_gt_map_cls)
+        for i in range(bsize):
+            self.gt_map_cls[self.scan_cnt] = batch_gt_map_cls[i]
+            self.pred_map_cls[self.scan_cnt] = batch_pred_map_cls[i]
+            self.scan_cnt += 1
+
+    def compute_metrics(self):
+        from .eval_det import eval_det_multiprocessing_wo_mesh
+        rec, _, ap = eval_det_multiprocessing_wo_mesh(self.pred_map_cls, self.gt_map_cls, ovthresh=self.ap_iou_thresh,
+                                                      device=self.device)
+        name = (lambda k: self.class2type_map[k]) if self.class2type_map else str
+        ret = {}
+        for key in sorted(ap.keys()):
+            ret['%s Average Precision' % name(key)] = ap[key]
+        ret['mAP'] = np.mean([v for v in ap.values() if not np.isnan(v)])
+        recalls = []
+        for key in sorted(ap.keys()):
+            try:
+                last = rec[key][-1]
+            except (TypeError, IndexError):      # class without predictions (rec == 0) or without detections
+                last = 0
+            ret['%s Recall' % name(key)] = last
+            recalls.append(last)
+        ret['AR'] = np.mean([v for v in recalls if not np.isnan(v)])
+        return ret
+
+    def reset(self):
+        self.gt_map_cls = {}
+        self.pred_map_cls = {}
+        self.scan_cnt = 0

@@ -29,6 +29,8 @@ class DatasetConfig:
     class_labels = ['bathtub', 'bed', 'bench', 'bookshelf', 'cabinet', 'chair', 'closet', 'desk',
                     'dishwasher', 'faucet', 'fridge', 'garbagecan', 'lamp', 'microwave', 'monitor',
                     'nightstand', 'sofa', 'stove', 'toilet', 'washingmachine', 'window', 'computer']
+    type2class = {cls: index for index, cls in enumerate(class_labels)}       # dataset_config.py:82-83
+    class2type = {index: cls for index, cls in enumerate(class_labels)}
 
 
 _BASE = {

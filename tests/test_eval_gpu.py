@@ -79,3 +79,32 @@ def test_far_box_filter_matches_delaunay_reference(dev):
     with torch.no_grad():
         ep, eval_dict, parsed = net.generate(data, eval=False)
     assert (eval_dict['pred_mask'] != z['g5far_pred_mask']).mean() <= 0.01
+
+
+def test_test_loop_metrics(dev):
+    """test_epoch-style loop: Tester.test_step over batches -> loss meters + APCalculator per IoU threshold.
+    The metric of the pipeline's own lists must equal the metric of the same lists evaluated pair by pair."""
+    from pose2room_amd.net_utils import eval_det, box_util
+    from pose2room_amd.p2rnet import testing
+    from pose2room_amd.p2rnet.training import ModuleWrapper
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    net, cfg = build('test', 256, device=dev, remove_far_box=True)
+    tester = testing.Tester(cfg, ModuleWrapper(net.to(dev)), dev)
+    batches = [make_batch(2, 256, seed=900 + i, device=dev) for i in range(2)]
+    logged = []
+    cfg.log_string = logged.append
+    out = testing.test(cfg, tester, batches, ap_device=dev)
+    assert set(out['loss']) >= {'total', 'vote_loss', 'center_loss', 'obj_acc'}
+    assert len(out['metrics']) == len(cfg.config['test']['ap_iou_thresholds'])
+    for m in out['metrics']:
+        assert 'mAP' in m and 'AR' in m and 0.0 <= m['AR'] <= 1.0
+    assert any(s.startswith('eval mAP') for s in logged)
+    # same lists, per-pair IoU callback on the CPU
+    with torch.no_grad():
+        _, calcs = testing.test_func(cfg, tester, batches, ap_device='cpu')
+    f = lambda a, b: box_util.box3d_iou(a, b)[0]       # noqa: E731
+    for calc, m in zip(calcs, out['metrics']):
+        _, _, ap = eval_det.eval_det_multiprocessing_wo_mesh(calc.pred_map_cls, calc.gt_map_cls, calc.ap_iou_thresh,
+                                                             get_iou_func=f)
+        vals = [v for v in ap.values() if not np.isnan(v)]
+        assert m['mAP'] == pytest.approx(np.mean(vals), abs=1e-9)
