@@ -179,19 +179,22 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
         a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
       }
     }
-    const int L = p.Lk[k];
+    const int Lp = p.Lk[k];
     const int lofs = p.Lofs[k];
 #pragma unroll
     for (int i = 0; i < GC_NT16; ++i) {
       int off[GC_MAXL];
       float cf[GC_MAXL];
+      int L = 0;                         // longest list among this n-tile's 16 columns (padded slots have coef 0)
 #pragma unroll
       for (int j = 0; j < GC_MAXL; ++j) {
-        const bool on = j < L;
+        const bool on = j < Lp;
         const int2 e = tbl[(on ? lofs + j : lofs) * p.V + wj[i]];
         off[j] = fbase[i] + e.x;
         cf[j] = (on && valid[i]) ? __int_as_float(e.y) : 0.f;
+        if (__ballot(cf[j] != 0.f) != 0ull) L = j + 1;
       }
+      if (L == 0) continue;              // plane k does not reach these columns
       switch (L) {
         case 1: agg_mfma16<1>(xg, off, cf, a, acc[i]); break;
         case 2:
@@ -292,7 +295,7 @@ struct DwSets {                   // host-balanced split of the planes over the 
   int plane[2][DW_PL];            // plane id or -1
 };
 
-// b[f] += sum_j coef * X[ci row][frame f, joint nbr_j]  for one plane; L compile-time.
+// b[f] += sum_j coef * X[ci row][frame f, joint nbr_j]  for one plane (accumulates into b).
 // L = compile-time list capacity (a few sizes only, to bound code size), Lr = real length.
 template <int L>
 __device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstride,
@@ -309,8 +312,6 @@ __device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstr
   for (int j = 0; j < L; ++j)
 #pragma unroll
     for (int f = 0; f < DW_F; ++f) xv[j][f] = xrow[f * V + e[j].x];
-#pragma unroll
-  for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
 #pragma unroll
   for (int j = 0; j < L; ++j) {
     const float cf = live ? __int_as_float(e[j].y) : 0.f;
@@ -347,15 +348,27 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
   const size_t row_stride = (size_t)p.T * p.V;
   const int n_groups = (p.V + 3) / 4;
 
+  // longest real list (non-zero coefficient) among the four joints of each (plane, joint group): the
+  // gathers of one MFMA step only need that many slots, and a group a plane does not reach is skipped
+  int *glen = reinterpret_cast<int *>(tbl + ltot * p.V);             // [K][DW_MAXV / 4]
+  __syncthreads();
+  for (int e = tid; e < p.K * n_groups; e += DW_THREADS) {
+    const int k = e / n_groups, wg = e - k * n_groups;
+    int m = 0;
+    for (int j = 0; j < p.Lk[k]; ++j)
+      for (int w = 4 * wg; w < min(4 * wg + 4, p.V); ++w)
+        if (__int_as_float(tbl[(p.Lofs[k] + j) * p.V + w].y) != 0.f) m = j + 1;
+    glen[k * (DW_MAXV / 4) + wg] = m;
+  }
+
   floatx4 acc[DW_PL][4];
-  int pl_k[DW_PL], pl_L[DW_PL], pl_row[DW_PL];   // this wave's planes, hoisted out of the loops (SGPRs)
+  int pl_k[DW_PL], pl_row[DW_PL];   // this wave's planes, hoisted out of the loops (SGPRs)
 #pragma unroll
   for (int kk = 0; kk < DW_PL; ++kk) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[kk][m] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int k = sets.plane[half][kk];
     pl_k[kk] = k;
-    pl_L[kk] = k >= 0 ? p.Lk[k] : 0;
     pl_row[kk] = k >= 0 ? p.Lofs[k] * p.V : 0;
   }
 
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
     const float *drow = dzs + r * row_len;               // + 16*m rows
     for (int wg = 0; wg < n_groups; ++wg) {
       const int w = 4 * wg + g;
+      const int *gl_w = glen + wg;
       const bool live = w < p.V;
       const int wc = live ? w : 0;
       float a[4][DW_F];
@@ -412,12 +426,19 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
         if (pl_k[kk] < 0) continue;                      // uniform
         float b[DW_F];
         const int2 *trow = tbl + pl_row[kk] + wc;
-        const int Lr = pl_L[kk];
+        const int Lr = __builtin_amdgcn_readfirstlane(gl_w[pl_k[kk] * (DW_MAXV / 4)]);
+        if (Lr == 0) continue;                           // all-zero aggregate: nothing to accumulate
+#pragma unroll
+        for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
+        // lists longer than six go in two passes: bounds the live gather registers (no scratch)
         if (Lr <= 1) dw_plane<1>(trow, p.V, xrow, p.V, live, Lr, b);
         else if (Lr <= 3) dw_plane<3>(trow, p.V, xrow, p.V, live, Lr, b);
-        else if (Lr <= 5) dw_plane<5>(trow, p.V, xrow, p.V, live, Lr, b);
-        else if (Lr <= 8) dw_plane<8>(trow, p.V, xrow, p.V, live, Lr, b);
-        else dw_plane<12>(trow, p.V, xrow, p.V, live, Lr, b);
+        else if (Lr <= 6) dw_plane<6>(trow, p.V, xrow, p.V, live, Lr, b);
+        else {
+          dw_plane<6>(trow, p.V, xrow, p.V, live, 6, b);
+          if (Lr <= 9) dw_plane<3>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
+          else dw_plane<6>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
+        }
 #pragma unroll
         for (int f = 0; f < DW_F; ++f)
 #pragma unroll
@@ -464,6 +485,15 @@ constexpr int DC_ROW4 = GC_NP + 1;  // float4 elements per row group (odd: sprea
 // Per-lane partial of dcoef for one (plane, n-tile): sum over this lane's 16 rows of
 // H[row][col] * X[row][(frame, neighbour_j)], for each of the L neighbours; reduced over
 // the four lane groups with LDS float atomics.
+// v summed over the four 16-lane rows of the wave (every lane gets the total):
+// v_permlane32_swap pairs rows {0,1} with {2,3}, v_permlane16_swap pairs odd with even rows.
+__device__ __forceinline__ float rows4_sum(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int L>
 __device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float4 *__restrict__ xs4, int g,
                                           const int2 *__restrict__ trow, int V, int fbase,
@@ -486,9 +516,14 @@ __device__ __forceinline__ void dc_reduce(const floatx4_t (&h)[4], const float4 
       part[j] = fmaf(h[m][3], xv.w, part[j]);
     }
   }
+  // sum over the four lane groups in the VALU (gfx950 lane swaps), then one LDS atomic per column
 #pragma unroll
-  for (int j = 0; j < L; ++j)
-    if (j < Lr) atomicAdd(dcs_row + j * V, part[j]);
+  for (int j = 0; j < L; ++j) part[j] = rows4_sum(part[j]);
+  if (g == 0) {
+#pragma unroll
+    for (int j = 0; j < L; ++j)
+      if (j < Lr) atomicAdd(dcs_row + j * V, part[j]);
+  }
 }
 
 __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, int n_seq, int ltot,
@@ -511,6 +546,29 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
   for (int e = tid; e < ltot * p.V; e += DC_THREADS) {
     tbl[e] = make_int2((int)nbr[e], 0);
     dcs[e] = 0.f;
+  }
+  __syncthreads();
+  // A tile's columns keep their joint across the persistent loop (column = frame * V + joint, tiles start at
+  // whole frames), so the longest real list among a wave's 16 columns is fixed per (n-tile, plane): lists
+  // are sorted and padded with joint 0, i.e. slot j >= 1 is real iff its entry is non-zero.
+  int tlen[GC_NT16];                       // plane k's value lives in lane k of the wave
+#pragma unroll
+  for (int i = 0; i < GC_NT16; ++i) {
+    const int col = (wave * GC_NT16 + i) * 16 + r;
+    const bool in = col < p.F * p.V;
+    const int w = in ? col % p.V : 0;
+    int mine = 0;
+    for (int k = 0; k < p.K; ++k) {
+      int len = in ? 1 : 0;
+      for (int j = 1; j < p.Lk[k]; ++j)
+        if (in && tbl[(p.Lofs[k] + j) * p.V + w].x != 0) len = j + 1;
+      // wave maximum by ballots over the candidate lengths
+      int m = 0;
+      for (int c = 1; c <= p.Lk[k]; ++c)
+        if (__ballot(len >= c) != 0ull) m = c;
+      if (lane == k) mine = m;
+    }
+    tlen[i] = mine;
   }
 
   const int total_tiles = n_seq * p.tiles_per_seq;
@@ -567,10 +625,10 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
           a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
         }
       }
-      const int L = p.Lk[k];
       const int lofs = p.Lofs[k];
 #pragma unroll
       for (int i = 0; i < GC_NT16; ++i) {
+        const int L = __builtin_amdgcn_readlane(tlen[i], k);   // longest real list in this n-tile
         floatx4_t h[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) h[m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -642,7 +700,8 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   }
   int row_len = DW_F * V;
   while (row_len % 32 != 2) ++row_len;   // row stride == 2 (mod 32): conflict-free column reads
-  const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2);
+  const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2) +
+                     (size_t)K * (DW_MAXV / 4) * sizeof(int);
   if (lds > 160 * 1024 || row_len > 256) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {

@@ -11,6 +11,10 @@ x = torch.randn(N, 64, T, V, device=dev); W = torch.randn(K * 64, 64, device=dev
 z = torch.empty_like(x)
 coef = gcn_tables.coefficients(torch.tensor(A, dtype=torch.float32, device=dev), gidx.to(dev)).contiguous()
 nb = nbr.to(dev)
+nbr_r, gidx_r, Lk_r = gcn_tables.build(A, transpose=True)
+coef_r = gcn_tables.coefficients(torch.tensor(A, dtype=torch.float32, device=dev), gidx_r.to(dev)).contiguous()
+nb_r = nbr_r.to(dev)
+ref = {}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'))):
     lib = ctypes.CDLL(so)
@@ -26,4 +30,16 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
         e0.record()
         for _ in range(5): call()
         e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / 5)
-    print(os.path.basename(so), ' '.join(f'{t:.3f}' for t in ts), 'ms')
+    zc = z.clone()
+    LkR = (ctypes.c_int * K)(*Lk_r)
+    def call_r():
+        assert lib.p2r_stgcn_gcn_forward(N, T, V, K, LkR, p(x), p(W), p(nb_r), p(coef_r), None, p(z), st) == 0
+    call_r(); tr = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): call_r()
+        e1.record(); e1.synchronize(); tr.append(e0.elapsed_time(e1) / 5)
+    ref.setdefault('c', zc); ref.setdefault('r', z.clone())
+    print(os.path.basename(so), 'col', ' '.join(f'{t:.3f}' for t in ts), 'row', ' '.join(f'{t:.3f}' for t in tr),
+          'ms  maxdiff %.2e %.2e' % ((zc - ref['c']).abs().max().item(), (z - ref['r']).abs().max().item()))
