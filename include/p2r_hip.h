@@ -160,11 +160,14 @@ int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
 
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65):
  * dw_partial [n_blocks][K][64][64], to be summed over the leading axis by the
- * caller (deterministic).  K <= 12, V <= 64. */
+ * caller (deterministic).  K <= 12, V <= 64.  colsum_partial, when not NULL,
+ * receives [n_blocks][64][V] partial sums of dz over samples and frames (the
+ * gradient of the bias table bias_cv of the forward), read from the same tiles. */
 int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host,
                               const float *x, const float *dz,
                               const uint8_t *nbr, const float *coef,
-                              int n_blocks, float *dw_partial, void *stream);
+                              int n_blocks, float *dw_partial, float *colsum_partial,
+                              void *stream);
 
 /* gradient w.r.t. the non-zero adjacency entries (reaches edge_importance,
  * stgcn.py:134): Wt [K][64][64] = transposed planes, nbr = the column lists;
@@ -217,18 +220,32 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
 /* ---- temporal (3,1) convolution of st_gcn_block, BatchNorm+ReLU fused on the input ---- */
 
 /* replaces tcn.0-tcn.2 (stgcn_layers.py:399-411): out[n,c,t,w] = bias[c] + sum_p sum_ci
- * W[p][c][ci] * h[n,ci,t+p-1,w], h = relu(x*scale+shift) when scale != NULL else x, zero
- * outside [0,T).  x, out (N,64,T,V); W [3][64][64]; scale/shift/bias [64] or NULL.  With
- * the taps reversed and transposed it yields the data gradient. */
-int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, const float *scale,
+ * W[p][c][ci] * h[n,ci,t+p-(taps-1)/2,w], h = relu(x*scale+shift) when scale != NULL else x,
+ * zero outside [0,T).  x, out (N,64,T,V); W [taps][64][64]; scale/shift/bias [64] or NULL.
+ * taps = 3 is the temporal convolution; taps = 1 the pointwise 64->64 Conv1d of the embedding
+ * MLPs (stgcn.py:46-63, sub_modules.py SingleConv 'cbr') with the preceding BatchNorm+ReLU
+ * fused the same way.  With the taps reversed and transposed it yields the data gradient. */
+int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const float *x, const float *scale,
                             const float *shift, const float *W, const float *bias,
                             float *out, void *stream);
 
-/* weight gradient: dw_partial [n_blocks][3][64][64] (summed by the caller) of
- * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-1,w] with h as above. */
-int p2r_stgcn_tconv_weight_grad(int N, int T, int V, const float *x, const float *scale,
+/* weight gradient: dw_partial [n_blocks][taps][64][64] (summed by the caller) of
+ * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-(taps-1)/2,w] with h as above. */
+int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,
                                 const float *shift, const float *dout, int n_blocks,
                                 float *dw_partial, void *stream);
+
+/* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
+
+/* pos_embed[0] / sk_feat[0] (stgcn.py:46-63): x (N,3,L), W [64][3], bias [64] or NULL ->
+ * out (N,64,L) = W . x + bias. */
+int p2r_embed3_forward(int N, int L, const float *x, const float *W, const float *bias,
+                       float *out, void *stream);
+
+/* its weight / bias gradient: partial [N*64][4] = per (sample, channel) row
+ * (sum dout*x0, sum dout*x1, sum dout*x2, sum dout); the caller sums over samples. */
+int p2r_embed3_weight_grad(int N, int L, const float *x, const float *dout, float *partial,
+                           void *stream);
 
 /* per-row column sums: x viewed as [rows][T][V] -> out_partial [rows][V] = sum over T
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */

@@ -47,7 +47,6 @@ struct GcnParams {
 
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GC_ROW = GC_NP + 1;   // (kept for sizing) row-major stride of earlier versions
 constexpr int GC_ROW4 = GC_NP + 1;  // float4 elements per group of four rows (X tile is row-interleaved)
 constexpr int GC_THREADS = 512;     // 8 waves: two per SIMD, so one wave's LDS / L2 waits hide
                                     // under the other's MFMAs
@@ -287,9 +286,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int DW_F = 4;
 constexpr int DW_MAXV = 64;
-constexpr int DW_MAXK = 11;
 constexpr int DW_PL = 6;          // planes per wave half (two halves cover up to 12 planes)
 constexpr int DW_THREADS = 512;
+constexpr int DW_CS = GC_C * DW_MAXV / DW_THREADS;   // (channel, joint) column sums owned per thread
 
 struct DwSets {                   // host-balanced split of the planes over the two wave halves
   int plane[2][DW_PL];            // plane id or -1
@@ -326,7 +325,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
                                                                const float *__restrict__ dz,
                                                                const uint8_t *__restrict__ nbr,
                                                                const float *__restrict__ coef,
-                                                               float *__restrict__ dw_partial) {
+                                                               float *__restrict__ dw_partial,
+                                                               float *__restrict__ colsum_partial) {
   extern __shared__ float lds[];
   float *dzs = lds;                                   // [64][row_len]
   float *xs = lds + GC_C * row_len;                   // [64][row_len]
@@ -351,6 +351,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
   // longest real list (non-zero coefficient) among the four joints of each (plane, joint group): the
   // gathers of one MFMA step only need that many slots, and a group a plane does not reach is skipped
   int *glen = reinterpret_cast<int *>(tbl + ltot * p.V);             // [K][DW_MAXV / 4]
+  float *cs = reinterpret_cast<float *>(glen + p.K * (DW_MAXV / 4)); // [64][V] running column sums of dZ
+  for (int e = tid; e < GC_C * p.V; e += DW_THREADS) cs[e] = 0.f;
   __syncthreads();
   for (int e = tid; e < p.K * n_groups; e += DW_THREADS) {
     const int k = e / n_groups, wg = e - k * n_groups;
@@ -409,6 +411,21 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
     }
     __syncthreads();
 
+    if (colsum_partial) {   // sum of dZ over the tile's frames per (channel, joint): the bias-table gradient
+#pragma unroll 1
+      for (int n = 0; n < DW_CS; ++n) {
+        const int idx = tid + DW_THREADS * n;
+        if (idx < GC_C * p.V) {
+          const int c = idx / p.V, w = idx - c * p.V;
+          const float *dp = dzs + c * row_len + w;
+          float sum = 0.f;
+#pragma unroll
+          for (int f = 0; f < DW_F; ++f) sum += dp[f * p.V];      // frames past the sequence end are zero-filled
+          cs[idx] += sum;                                         // element owned by this thread: no atomics
+        }
+      }
+    }
+
     const float *xrow = xs + (16 * nt + r) * row_len;   // this lane's ci row
     const float *drow = dzs + r * row_len;               // + 16*m rows
     for (int wg = 0; wg < n_groups; ++wg) {
@@ -448,6 +465,13 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
     }
   }
 
+  if (colsum_partial) {
+#pragma unroll
+    for (int n = 0; n < DW_CS; ++n) {
+      const int idx = tid + DW_THREADS * n;
+      if (idx < GC_C * p.V) colsum_partial[(size_t)blockIdx.x * GC_C * p.V + idx] = cs[idx];
+    }
+  }
   // partial[block][k][c][ci]: D[row = 4*g + q][col = r] -> c = 16*m + row, ci = 16*nt + r
   float *out = dw_partial + (size_t)blockIdx.x * p.K * GC_C * GC_C;
 #pragma unroll
@@ -673,11 +697,12 @@ static int gcn_fill_params(GcnParams &p, int T, int V, int K, const int *Lk_host
 }
 
 // dW partials: x, dz (N,64,T,V) -> dw_partial [n_blocks][K][64][64]; the caller sums
-// over the leading axis.  Returns the number of workgroups used through *n_blocks
+// over the leading axis.  colsum_partial (optional) [n_blocks][64][V] = per-workgroup sums of dz
+// over samples and frames (gradient of the bias table), also summed by the caller.  Returns the number of workgroups used through *n_blocks
 // when dw_partial is NULL (size query), else launches.  K must be 11.
 extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host, const float *x,
                                          const float *dz, const uint8_t *nbr, const float *coef,
-                                         int n_blocks, float *dw_partial, void *stream) {
+                                         int n_blocks, float *dw_partial, float *colsum_partial, void *stream) {
   GcnParams p;
   const int ltot = gcn_fill_params(p, T, V, K, Lk_host, DW_F);
   if (ltot < 0) return ltot;
@@ -701,7 +726,7 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   int row_len = DW_F * V;
   while (row_len % 32 != 2) ++row_len;   // row stride == 2 (mod 32): conflict-free column reads
   const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2) +
-                     (size_t)K * (DW_MAXV / 4) * sizeof(int);
+                     (size_t)K * (DW_MAXV / 4) * sizeof(int) + (size_t)GC_C * V * sizeof(float);
   if (lds > 160 * 1024 || row_len > 256) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
@@ -711,7 +736,7 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
     attr_set = true;
   }
   hipLaunchKernelGGL(gcn_dw_kernel, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
-                     row_len, ltot, x, dz, nbr, coef, dw_partial);
+                     row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -31,30 +31,33 @@ constexpr int TC_NT = 3;                  // n-tiles per wave
 // Persistent: each workgroup walks tiles blockIdx.x, +gridDim.x, ...; the global loads of the
 // NEXT tile are issued into registers before the MFMA phase of the current one, so HBM latency
 // and transfer hide under compute even though only one workgroup fits a CU (LDS).
+template <int TAPS>
 __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
     int n_seq, int T, int V, int F, int tiles_per_seq, int row_len, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ W,
     const float *__restrict__ bias, float *__restrict__ out) {
-  extern __shared__ float hs[];   // [64][row_len], frames t0-1 .. t0+F
+  extern __shared__ float hs[];   // [64][row_len], frames t0-HALO .. t0+F-1+HALO
+  constexpr int HALO = (TAPS - 1) / 2;
+  constexpr int NCH = TAPS == 1 ? TC_NPO / 64 : 8;   // 64-column chunks per tile row (tile + halo <= 64 * NCH)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const size_t row_stride = (size_t)T * V;
   const int total_tiles = n_seq * tiles_per_seq;
 
-  float pre[8][8];                 // this lane's share of a tile: 8 rows (wave, wave+8, ..) x 8 chunks
+  float pre[8][NCH];               // this lane's share of a tile: 8 rows (wave, wave+8, ..) x NCH chunks
   auto issue_loads = [&](int tile) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * F;
     const int frames = min(F, T - t0);
-    const int in_cols = (frames + 2) * V;
-    const long long col0 = (long long)(t0 - 1) * V;
+    const int in_cols = (frames + 2 * HALO) * V;
+    const long long col0 = (long long)(t0 - HALO) * V;
     const float *xg = x + (size_t)seq * TC_C * row_stride;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       const float *src = xg + (size_t)(wave + 8 * h) * row_stride;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int q = lane + 64 * i;
         const long long gc = col0 + q;
         const bool in = q < in_cols && gc >= 0 && gc < (long long)row_stride;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       const int c = wave + 8 * h;
       const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int q = lane + 64 * i;
         float v = pre[h][i];
         if (v != v) v = 0.f;                                   // outside the sequence / tile
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       for (int m = 0; m < 4; ++m) acc[i][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
 
     const float *hg = hs + g * 16 * row_len;
-    for (int ph = 0; ph < 6; ++ph) {           // (tap p, half of the 16 k-steps): keeps A operands at 32 VGPRs
+#pragma unroll 1
+    for (int ph = 0; ph < 2 * TAPS; ++ph) {    // (tap p, half of the 16 k-steps): keeps A operands at 32 VGPRs
       const int p = ph >> 1, hf = ph & 1;
       float a[4][8];                           // W[p][row 16m + r][ci 16g + 8hf .. +8)
 #pragma unroll
@@ -152,13 +156,16 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
 // tiles of accumulators; reduction steps of 4 consecutive columns.
 constexpr int TW_F = 4;
 
+template <int TAPS>
 __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
     float *__restrict__ dw_partial) {
   extern __shared__ float lds[];
   float *ds = lds;                       // [64][row_d]   dout tile, frames t0 .. t0+F-1
-  float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-1 .. t0+F
+  float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-HALO .. t0+F-1+HALO
+  constexpr int HALO = (TAPS - 1) / 2;
+  constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
@@ -167,9 +174,13 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
   const int total_tiles = n_seq * tiles_per_seq;
   const size_t row_stride = (size_t)T * V;
 
-  floatx4c acc[3][2];
+  // pad columns past the staged chunks (row strides are rounded up) are read by the last partial
+  // 4-column step: keep them zero
+  for (int e = tid; e < TC_C * (row_d + row_h); e += TC_THREADS) lds[e] = 0.f;
+
+  floatx4c acc[TAPS][2];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < TAPS; ++p)
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[p][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
 
@@ -180,19 +191,19 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     const int ncols = frames * V;
     const float *xg = x + (size_t)seq * TC_C * row_stride;
     const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
-    const long long col0 = (long long)(t0 - 1) * V;
+    const long long col0 = (long long)(t0 - HALO) * V;
     __syncthreads();
 #pragma unroll 1
     for (int c = wave; c < TC_C; c += TC_THREADS / 64) {
       const float *sx = xg + (size_t)c * row_stride;
       const float *sd = dg + (size_t)c * row_stride;
       const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
-      float vh[6], vd[4];
+      float vh[NH], vd[4];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
         const long long gc = col0 + q;
-        const bool in = q < (frames + 2) * V && gc >= 0 && gc < (long long)row_stride;
+        const bool in = q < (frames + 2 * HALO) * V && gc >= 0 && gc < (long long)row_stride;
         vh[i] = in ? sx[in ? gc : 0] : 0.f;
         if (scale && in) vh[i] = fmaxf(fmaf(vh[i], sc, sh), 0.f);
       }
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
         vd[i] = q < ncols ? sd[q] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
         if (q < row_h) hs[c * row_h + q] = vh[i];
       }
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     for (int s = 0; s < steps; ++s) {
       const float a0 = drow[4 * s], a1 = drow[16 * row_d + 4 * s];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < TAPS; ++p) {
         const float b = hrow[p * V + 4 * s];
         acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[p][0], 0, 0, 0);
         acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[p][1], 0, 0, 0);
@@ -228,9 +239,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     }
   }
   // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 32*mh + 16*m + row, ci = 16*nt + r
-  float *outp = dw_partial + (size_t)blockIdx.x * 3 * TC_C * TC_C;
+  float *outp = dw_partial + (size_t)blockIdx.x * TAPS * TC_C * TC_C;
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < TAPS; ++p)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -240,24 +251,24 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
 
 }  // namespace
 
-// x (N,64,T,V); W [3][64][64] (plane p = temporal tap dt = p-1, row = output channel);
-// scale/shift [64] or NULL (input transform relu(x*scale+shift)); bias [64] or NULL.
-extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, const float *scale,
-                                       const float *shift, const float *W, const float *bias, float *out,
-                                       void *stream) {
-  if (N < 0 || T <= 0 || V <= 0 || V > 128) return P2R_EINVAL;
-  if (N == 0) return P2R_OK;
+// x (N,64,T,V); W [taps][64][64] (plane p = temporal tap dt = p - (taps-1)/2, row = output channel);
+// scale/shift [64] or NULL (input transform relu(x*scale+shift)); bias [64] or NULL.  taps = 3: the
+// (3,1) temporal convolution; taps = 1: a pointwise 64->64 convolution over the same layout.
+template <int TAPS>
+static int tconv_forward_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                                const float *W, const float *bias, float *out, void *stream) {
+  constexpr int HALO = (TAPS - 1) / 2;
   int F = TC_NPO / V;
   if (F < 1) return P2R_EINVAL;
   if (F > T) F = T;
   const int tiles_per_seq = p2r_cdiv(T, F);
-  int row_len = (F + 2) * V;
+  int row_len = (F + 2 * HALO) * V;
   if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
   const size_t lds = (size_t)TC_C * row_len * sizeof(float);
   if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)tconv_fused_kernel,
+    hipError_t e = hipFuncSetAttribute((const void *)tconv_fused_kernel<TAPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -265,33 +276,50 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, const float *x, cons
   const long long tiles = (long long)N * tiles_per_seq;
   if (tiles > 0x7fffffffLL) return P2R_EINVAL;
   const int blocks = (int)(tiles < 256 ? tiles : 256);      // persistent: one workgroup per CU
-  hipLaunchKernelGGL(tconv_fused_kernel, dim3(blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V, F,
-                     tiles_per_seq, row_len, x, scale, shift, W, bias, out);
+  hipLaunchKernelGGL(tconv_fused_kernel<TAPS>, dim3(blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
+                     F, tiles_per_seq, row_len, x, scale, shift, W, bias, out);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
 
-// dw_partial [n_blocks][3][64][64], summed over the leading axis by the caller.
-extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, const float *x, const float *scale,
-                                           const float *shift, const float *dout, int n_blocks,
-                                           float *dw_partial, void *stream) {
-  if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1) return P2R_EINVAL;
+extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const float *x, const float *scale,
+                                       const float *shift, const float *W, const float *bias, float *out,
+                                       void *stream) {
+  if (N < 0 || T <= 0 || V <= 0 || V > 128 || (taps != 1 && taps != 3)) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
+  return taps == 3 ? tconv_forward_launch<3>(N, T, V, x, scale, shift, W, bias, out, stream)
+                   : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stream);
+}
+
+template <int TAPS>
+static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                           const float *dout, int n_blocks, float *dw_partial, void *stream) {
+  constexpr int HALO = (TAPS - 1) / 2;
   int row_d = TW_F * V + 3;                      // room for the last (partial) 4-column step
   while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
-  int row_h = (TW_F + 2) * V + 3;
+  int row_h = (TW_F + 2 * HALO) * V + 3;
   while (row_h % 32 != 2) ++row_h;
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
-  if (lds > 160 * 1024 || row_d > 256 || row_h > 384) return P2R_EINVAL;
+  if (lds > 160 * 1024 || TW_F * V > 256 || (TW_F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)tconv_dw_kernel,
+    hipError_t e = hipFuncSetAttribute((const void *)tconv_dw_kernel<TAPS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(tconv_dw_kernel, dim3(n_blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
+  hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
                      row_d, row_h, x, scale, shift, dout, dw_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
+}
+
+// dw_partial [n_blocks][taps][64][64], summed over the leading axis by the caller.
+extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,
+                                           const float *shift, const float *dout, int n_blocks,
+                                           float *dw_partial, void *stream) {
+  if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1 || (taps != 1 && taps != 3)) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  return taps == 3 ? tconv_dw_launch<3>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, stream)
+                   : tconv_dw_launch<1>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, stream);
 }

@@ -96,10 +96,15 @@ class _GraphConv(Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[1]:
                 part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
+                # the bias-table gradient (column sums of dz) rides on the same pass over dz
+                bpart = torch.empty((_N_BLOCKS, C, V), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
                 _lib.check(lib.p2r_stgcn_gcn_weight_grad(
                     N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(t['nbr_c']),
-                    _lib.ptr(coef_c.contiguous()), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_weight_grad")
+                    _lib.ptr(coef_c.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
+                    "stgcn_gcn_weight_grad")
                 dW = part.sum(0).view(K * C, C)
+                if bpart is not None:
+                    dbias = bpart.sum(0)                                   # (C, V)
             if ctx.needs_input_grad[2] and not merged:
                 ltot = coef_c.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
@@ -107,7 +112,7 @@ class _GraphConv(Function):
                     N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wt), _lib.ptr(t['nbr_c']),
                     _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
                 dcoef = part.sum(0)
-        if ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[4] and dbias is None:
             part = torch.empty((N * C, V), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")

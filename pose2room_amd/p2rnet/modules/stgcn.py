@@ -70,10 +70,24 @@ class STGCN(nn.Module):
         raise NotImplementedError
 
     @staticmethod
-    def _mlp(seq, x):
-        """Run a `_point_mlp` stack; on the GPU each conv+BatchNorm+ReLU stage uses the fused
-        BatchNorm/ReLU kernels instead of separate normalisation and activation passes."""
-        from .. import bn_op
+    def _mlp(seq, x, inner):
+        """Run a `_point_mlp` stack (conv-BN-ReLU, conv-BN-ReLU, conv) on x (B,3,L), L = rows * inner.
+        On the GPU: the 3->64 layer is a streaming kernel, and each BatchNorm+ReLU is folded into the
+        following pointwise 64->64 convolution (one pass per layer instead of GEMM + normalise +
+        activate); elsewhere the plain module chain runs."""
+        from .. import bn_op, tconv_op
+        s0, s1, s2 = seq
+        fused = (x.is_cuda and len(seq) == 3 and hasattr(s0, 'batchnorm') and hasattr(s1, 'batchnorm')
+                 and not hasattr(s2, 'batchnorm') and tconv_op.supported_embed3(x, s0.conv)
+                 and x.shape[2] % inner == 0 and inner <= 64)
+        if fused:
+            z = tconv_op.embed3(x, s0.conv).view(x.shape[0], 64, x.shape[2] // inner, inner)
+            fused = tconv_op.supported_pointwise(z, s0.batchnorm, s1.conv) and \
+                tconv_op.supported_pointwise(z, s1.batchnorm, s2.conv)
+            if fused:
+                z = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv)
+                z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv)
+                return z.view(x.shape[0], 64, x.shape[2])
         for stage in seq:
             if x.is_cuda and hasattr(stage, 'batchnorm') and hasattr(stage, 'ReLU') and \
                     bn_op.supported(x, stage.batchnorm):
@@ -93,10 +107,10 @@ class STGCN(nn.Module):
             torch.arange(-self.knn // 2, self.knn // 2, device=device).unsqueeze(0)
         win = win.clamp_(0, n_frames - 1)                                      # (T,knn)
         offs = hip[:, win] - hip.unsqueeze(2)                                  # (B,T,knn,3)
-        pe = self._mlp(self.pos_embed, offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2))
+        pe = self._mlp(self.pos_embed, offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2).contiguous(), self.knn)
         pe = pe.view(n_batch, -1, n_frames, self.knn).mean(dim=3)             # (B,64,T)
         rel = input_joints - input_joints[:, :, [self.origin_joint_id]]
-        sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2))
+        sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2).contiguous(), n_joints)
         return sk.view(n_batch, -1, n_frames, n_joints) + pe.unsqueeze(-1)
 
     def forward(self, input_joints, end_points=None):
@@ -108,13 +122,21 @@ class STGCN(nn.Module):
         for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
             x, _ = gcn(x, self.A * importance)
 
-        x = x.transpose(2, 3).reshape(n_batch, -1, n_frames)   # (B, 64*J, T), channel-major like the reference
-        seed_features = self.conv_joint(x).transpose(1, 2)      # (B,T,256)
-
         seed_skeleton = torch.gather(
             input_joints, 1, seed_inds[:, :, None, None].expand(n_batch, self.n_seeds, n_joints, n_dim))
-        seed_features = torch.gather(
-            seed_features, 1, seed_inds.unsqueeze(-1).expand(n_batch, self.n_seeds, seed_features.size(-1)))
+        if self.n_seeds < n_frames:
+            # conv_joint is pointwise in time (kernel 1), so the reference's conv-then-gather
+            # (stgcn.py:142-149) equals gather-then-conv: only the seed frames go through the
+            # 3392 -> 256 GEMM, and the frame gather doubles as the re-layout to (.., 64*J) rows.
+            rows = x.permute(0, 2, 1, 3)[torch.arange(n_batch, device=x.device)[:, None], seed_inds]   # (B,S,64,J)
+            seed_features = torch.nn.functional.linear(                 # (B,S,256); feature order c*J + j as in
+                rows.reshape(n_batch, self.n_seeds, -1),                # the reference's (B, 64*J, T) layout
+                self.conv_joint.weight.squeeze(-1), self.conv_joint.bias)
+        else:
+            x = x.transpose(2, 3).reshape(n_batch, -1, n_frames)
+            seed_features = self.conv_joint(x).transpose(1, 2)          # (B,T,256)
+            seed_features = torch.gather(
+                seed_features, 1, seed_inds.unsqueeze(-1).expand(n_batch, self.n_seeds, seed_features.size(-1)))
         end_points['seed_inds'] = seed_inds
         end_points['seed_skeleton'] = seed_skeleton[..., :3]
         end_points['seed_features'] = seed_features

@@ -1,4 +1,4 @@
-"""BatchNorm -> ReLU -> temporal (3,1) convolution as one fused op (csrc/stgcn_tconv.hip).
+"""BatchNorm -> ReLU -> temporal (3,1) / pointwise convolution as one fused op (csrc/stgcn_tconv.hip).
 
 `bn_relu_tconv(z, bn, conv)` equals `conv(relu(bn(z)))` for the `tcn.0 / tcn.1 / tcn.2` stage of
 the reference's st_gcn_block (stgcn_layers.py:399-411) with a 64->64 (3,1) conv, stride 1,
@@ -6,6 +6,10 @@ padding (1,0).  The normalised activation is produced while the kernel stages it
 and never written to HBM; the backward recomputes the ReLU mask from z.  Differentiable
 w.r.t. z, bn.weight, bn.bias, conv.weight, conv.bias; updates the BatchNorm running
 statistics in training mode like nn.BatchNorm2d.
+
+The same op with a single tap serves the `cbr -> cbr -> c` embedding MLPs (stgcn.py:46-63): the
+BatchNorm + ReLU of stage i is folded into the pointwise 64->64 Conv1d of stage i+1
+(`bn_relu_pointwise`), and their 3->64 first layer has its own streaming kernel (`embed3`).
 """
 import torch
 from torch.autograd import Function
@@ -20,7 +24,7 @@ def _tconv(x, scale, shift, W3, bias):
     N, C, T, V = x.shape
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().p2r_stgcn_tconv_forward(N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
+        _lib.check(_lib.lib().p2r_stgcn_tconv_forward(N, T, V, W3.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
                                                       _lib.ptr(W3), _lib.ptr(bias), _lib.ptr(out),
                                                       _lib.current_stream(x.device)), "stgcn_tconv_forward")
     return out
@@ -32,11 +36,13 @@ class _BNReLUTConv(Function):
         z = z.contiguous()
         scale = (gamma * invstd).contiguous()
         shift = (beta - mean * scale).contiguous()
-        W3 = weight.reshape(64, 64, 3).permute(2, 0, 1).contiguous()            # [tap][c][ci]
+        taps = weight.numel() // (64 * 64)
+        W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
         u = _tconv(z, scale, shift, W3, bias.contiguous() if bias is not None else None)
         ctx.save_for_backward(z, gamma, mean, invstd, scale, shift, W3)
         ctx.train = train
         ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
         return u
 
     @staticmethod
@@ -71,11 +77,12 @@ class _BNReLUTConv(Function):
                                             _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
                                             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
                        "bn_bwd_apply")
-            part = torch.empty((_N_BLOCKS, 3, 64, 64), dtype=torch.float32, device=dev)
-            _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
+            taps = W3.shape[0]
+            part = torch.empty((_N_BLOCKS, taps, 64, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
                                                        _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), st),
                        "stgcn_tconv_weight_grad")
-            dW = part.sum(0).permute(1, 2, 0).reshape(64, 64, 3, 1).contiguous()
+            dW = part.sum(0).permute(1, 2, 0).reshape(ctx.wshape).contiguous()
             if ctx.has_bias:
                 sp = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_bn_stats(N * C, L, _lib.ptr(du), _lib.ptr(sp), st), "bn_stats")
@@ -88,6 +95,56 @@ def supported(z, bn, conv):
             and conv.in_channels == 64 and conv.out_channels == 64 and tuple(conv.kernel_size) == (3, 1)
             and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 0) and tuple(conv.dilation) == (1, 1)
             and conv.groups == 1 and bn_op.supported(z, bn))
+
+
+def supported_pointwise(z, bn, conv):
+    """z (B,64,T,V) view of a (B,64,L) activation; conv = Conv1d(64, 64, 1)."""
+    return (z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and z.shape[1] == 64 and z.shape[3] <= 64
+            and isinstance(conv, torch.nn.Conv1d) and conv.in_channels == 64 and conv.out_channels == 64
+            and tuple(conv.kernel_size) == (1,) and tuple(conv.stride) == (1,) and tuple(conv.padding) == (0,)
+            and conv.groups == 1 and bn_op.supported(z, bn))
+
+
+class _Embed3(Function):
+    """Conv1d(3 -> 64, kernel 1) on (B,3,L): streaming kernels of csrc/embed.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        B, _, L = x.shape
+        out = torch.empty((B, 64, L), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().p2r_embed3_forward(B, L, _lib.ptr(x), _lib.ptr(weight.reshape(64, 3).contiguous()),
+                                                     _lib.ptr(bias.contiguous() if bias is not None else None),
+                                                     _lib.ptr(out), _lib.current_stream(x.device)), "embed3_forward")
+        ctx.save_for_backward(x)
+        ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        assert not ctx.needs_input_grad[0], "embed3: the joint coordinates are inputs, no data gradient"
+        dout = dout.contiguous()
+        B, _, L = x.shape
+        part = torch.empty((B * 64, 4), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().p2r_embed3_weight_grad(B, L, _lib.ptr(x), _lib.ptr(dout), _lib.ptr(part),
+                                                         _lib.current_stream(x.device)), "embed3_weight_grad")
+        tot = part.view(B, 64, 4).double().sum(0).float()
+        return None, tot[:, :3].reshape(ctx.wshape).contiguous(), (tot[:, 3].contiguous() if ctx.has_bias else None)
+
+
+def supported_embed3(x, conv):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] == 3 and not x.requires_grad
+            and isinstance(conv, torch.nn.Conv1d) and conv.in_channels == 3 and conv.out_channels == 64
+            and tuple(conv.kernel_size) == (1,) and tuple(conv.stride) == (1,) and tuple(conv.padding) == (0,)
+            and conv.groups == 1)
+
+
+def embed3(x, conv):
+    return _Embed3.apply(x, conv.weight, conv.bias)
 
 
 def bn_relu_tconv(z, bn, conv):

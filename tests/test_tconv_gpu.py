@@ -45,3 +45,67 @@ def test_bn_relu_tconv(dev, N, T, V, train):
         close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)
         close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
+
+
+@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 20), (3, 9, 20), (2, 130, 53), (2, 17, 64)])
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_relu_pointwise(dev, N, T, V, train):
+    """Single-tap form: BatchNorm1d -> ReLU -> Conv1d(64, 64, 1) of the embedding MLPs (stgcn.py:46-63)."""
+    from pose2room_amd.p2rnet import tconv_op
+    torch.manual_seed(N * 10 + T)
+    bn_ref = torch.nn.BatchNorm1d(64).to(dev)
+    conv_ref = torch.nn.Conv1d(64, 64, 1).to(dev)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.5, 0.5)
+        bn_ref.running_mean.uniform_(-0.2, 0.2); bn_ref.running_var.uniform_(0.5, 2.0)
+    bn_new, conv_new = copy.deepcopy(bn_ref), copy.deepcopy(conv_ref)
+    bn_ref, conv_ref = bn_ref.double(), conv_ref.double()
+    bn_ref.train(train); bn_new.train(train)
+    z = torch.randn(N, 64, T * V, device=dev) * 1.5 + 0.3
+    go = torch.randn(N, 64, T * V, device=dev)
+
+    zr = z.double().clone().requires_grad_(True)
+    ur = conv_ref(torch.relu(bn_ref(zr)))
+    ur.backward(go.double())
+    zn = z.clone().requires_grad_(True)
+    z4 = zn.view(N, 64, T, V)
+    assert tconv_op.supported_pointwise(z4, bn_new, conv_new)
+    un = tconv_op.bn_relu_tconv(z4, bn_new, conv_new).view(N, 64, T * V)
+    un.backward(go)
+
+    def close(a, b, what, tol=3e-5):
+        scale = b.abs().max().item() + 1e-12
+        err = (a.double() - b.double()).abs().max().item()
+        assert err <= tol * scale, f"{what}: {err:.3e} vs {scale:.3e}"
+
+    close(un, ur, "u")
+    close(zn.grad, zr.grad, "dz", 1e-4)
+    assert conv_new.weight.grad.shape == conv_new.weight.shape
+    close(conv_new.weight.grad, conv_ref.weight.grad, "dW", 1e-4)
+    close(conv_new.bias.grad, conv_ref.bias.grad, "dbias", 1e-4)
+    if train:
+        close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)
+        close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
+        close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
+
+
+@pytest.mark.parametrize("B,L", [(2, 53 * 40), (1, 7), (3, 20 * 33 + 1), (2, 4096)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_embed3(dev, B, L, bias):
+    """Conv1d(3 -> 64, 1): forward and weight / bias gradients against torch in fp64."""
+    from pose2room_amd.p2rnet import tconv_op
+    torch.manual_seed(B + L)
+    conv = torch.nn.Conv1d(3, 64, 1, bias=bias).to(dev)
+    ref = copy.deepcopy(conv).double()
+    x = torch.randn(B, 3, L, device=dev)
+    go = torch.randn(B, 64, L, device=dev)
+    assert tconv_op.supported_embed3(x, conv)
+    out = tconv_op.embed3(x, conv)
+    out.backward(go)
+    want = ref(x.double())
+    want.backward(go.double())
+    assert out.shape == (B, 64, L)
+    torch.testing.assert_close(out.double(), want, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(conv.weight.grad.double(), ref.weight.grad, rtol=1e-4, atol=1e-4 * ref.weight.grad.abs().max().item())
+    if bias:
+        torch.testing.assert_close(conv.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-4 * ref.bias.grad.abs().max().item())
