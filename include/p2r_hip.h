@@ -152,11 +152,18 @@ int p2r_nms3d(int B, int K, int stride, const double *boxes,
  * [sum_k Lk][V] (j-th source joint of column w in plane k and its A*importance
  * value, zero-padded), Lk_host[K] on the HOST; bias_cv [64][V] = the conv bias
  * pushed through the graph product, or NULL.  Called with transposed planes and
- * row lists it yields the data gradient.  K <= 16, Lk <= 12, V <= 128. */
+ * row lists it yields the data gradient.  K <= 16, Lk <= 12, V <= 128.
+ * Table convention (all graph-conv entry points): each list is sorted by joint
+ * index and padded with (joint 0, coefficient 0), so a slot j >= 1 holding joint 0
+ * is padding; the kernels skip the padded tail of a tile's lists.
+ * stats_partial, when not NULL, receives [N * ceil(T / (384 / V))][64][2]: per
+ * workgroup (sum, sum of squares) of z per channel -- the batch statistics the
+ * BatchNorm after the graph conv needs (tcn.0, stgcn_layers.py:400), taken from the
+ * accumulators instead of a second pass over z. */
 int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
                           const float *x, const float *W, const uint8_t *nbr,
                           const float *coef, const float *bias_cv, float *z,
-                          void *stream);
+                          float *stats_partial, void *stream);
 
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65):
  * dw_partial [n_blocks][K][64][64], to be summed over the leading axis by the
@@ -224,16 +231,21 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
  * zero outside [0,T).  x, out (N,64,T,V); W [taps][64][64]; scale/shift/bias [64] or NULL.
  * taps = 3 is the temporal convolution; taps = 1 the pointwise 64->64 Conv1d of the embedding
  * MLPs (stgcn.py:46-63, sub_modules.py SingleConv 'cbr') with the preceding BatchNorm+ReLU
- * fused the same way.  With the taps reversed and transposed it yields the data gradient. */
+ * fused the same way.  With the taps reversed and transposed it yields the data gradient.
+ * stats_partial, when not NULL, receives [*n_partials][64][2] per-workgroup (sum, sum of
+ * squares) of out per channel (batch statistics for the BatchNorm that follows);
+ * *n_partials (when not NULL) returns the number of workgroups, also when out == NULL
+ * (size query, nothing is launched). */
 int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const float *x, const float *scale,
                             const float *shift, const float *W, const float *bias,
-                            float *out, void *stream);
+                            float *out, float *stats_partial, int *n_partials, void *stream);
 
 /* weight gradient: dw_partial [n_blocks][taps][64][64] (summed by the caller) of
- * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-(taps-1)/2,w] with h as above. */
+ * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-(taps-1)/2,w] with h as above; dbias_partial,
+ * when not NULL, [n_blocks][64] = per-workgroup sums of dout per channel (bias gradient). */
 int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,
                                 const float *shift, const float *dout, int n_blocks,
-                                float *dw_partial, void *stream);
+                                float *dw_partial, float *dbias_partial, void *stream);
 
 /* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
 

@@ -41,3 +41,13 @@ __device__ __forceinline__ float p2r_sqdist(float ax, float ay, float az,
   const float dx = ax - bx, dy = ay - by, dz = az - bz;
   return dx * dx + dy * dy + dz * dz;
 }
+
+// Sum of v over the 16 lanes of a DPP row (lanes 16g .. 16g+15); every lane of the row gets the total.
+// Pure VALU (quad_perm / row_half_mirror / row_mirror butterflies), no LDS traffic.
+__device__ __forceinline__ float p2r_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v;
+}

@@ -104,10 +104,11 @@ __device__ __forceinline__ void agg_mfma16(const float4 *__restrict__ xg4, const
 __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
     GcnParams p, int ltot, const float *__restrict__ x, const float *__restrict__ W,
     const uint8_t *__restrict__ nbr, const float *__restrict__ coef,
-    const float *__restrict__ bias_cv, float *__restrict__ z) {
+    const float *__restrict__ bias_cv, float *__restrict__ z, float *__restrict__ stats_partial) {
   extern __shared__ float xs[];                       // [16 row groups][GC_ROW4] float4, then the int2 table
   float4 *xs4 = reinterpret_cast<float4 *>(xs);
   int2 *tbl = reinterpret_cast<int2 *>(xs + 16 * GC_ROW4 * 4);
+  float *rowstat = reinterpret_cast<float *>(tbl + ltot * p.V);   // [64][2] per-row (sum, sum of squares) of the output tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   }
   for (int e = tid; e < ltot * p.V; e += GC_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
+  if (tid < 2 * GC_C) rowstat[tid] = 0.f;
   __syncthreads();
 
   int colv[GC_NT16], fbase[GC_NT16], wj[GC_NT16];
@@ -209,6 +211,11 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   }
 
   // ---- epilogue: 16x16 tile D[row = 4g + q][col = r]
+  float s1[4][4], s2[4][4];            // this lane's share of the per-row output statistics
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s1[m][q] = s2[m][q] = 0.f;
 #pragma unroll
   for (int i = 0; i < GC_NT16; ++i) {
     if (!valid[i]) continue;
@@ -220,8 +227,26 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
         float v = acc[i][m][q];
         if (bias_cv) v += bias_cv[row * p.V + wj[i]];
         zg[(size_t)row * row_stride + colv[i]] = v;
+        s1[m][q] += v;
+        s2[m][q] = fmaf(v, v, s2[m][q]);
       }
     }
+  }
+  // The BatchNorm that follows (tcn.0, stgcn_layers.py:400) needs sum / sum of squares per channel of exactly
+  // this output: reduce them here instead of re-reading z -- 16 lanes (DPP), then the 8 waves (LDS atomics).
+  if (stats_partial) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = p2r_row16_sum(s1[m][q]), b = p2r_row16_sum(s2[m][q]);
+        if (r == 0) {
+          atomicAdd(rowstat + 2 * (16 * m + 4 * g + q), a);
+          atomicAdd(rowstat + 2 * (16 * m + 4 * g + q) + 1, b);
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * GC_C) stats_partial[(size_t)blockIdx.x * 2 * GC_C + tid] = rowstat[tid];
   }
 }
 
@@ -229,10 +254,11 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
 
 // x (N,64,T,V) -> z (N,64,T,V).  W [K][64][64] (row = output channel); nbr u8 /
 // coef f32 tables [sum_k L_k][V] (column-wise neighbour lists of plane k, padded
-// with coef 0); Lk[K] on the host; bias_cv [64][V] or NULL.
+// with coef 0); Lk[K] on the host; bias_cv [64][V] or NULL.  stats_partial (optional)
+// [N * ceil(T / F)][64][2], F = 384 / V: per-workgroup (sum, sum of squares) of z per channel.
 extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host, const float *x,
                                      const float *W, const uint8_t *nbr, const float *coef,
-                                     const float *bias_cv, float *z, void *stream) {
+                                     const float *bias_cv, float *z, float *stats_partial, void *stream) {
   if (N < 0 || T <= 0 || V <= 0 || V > 128 || K <= 0 || K > GC_MAXK) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   GcnParams p;
@@ -250,7 +276,7 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
   }
   const long long blocks = (long long)N * p.tiles_per_seq;
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
-  const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2);
+  const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2) + 2 * GC_C * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
@@ -260,7 +286,7 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
     attr_set = true;
   }
   hipLaunchKernelGGL(gcn_fused_kernel, dim3((unsigned)blocks), dim3(GC_THREADS), lds,
-                     p2r_stream(stream), p, ofs, x, W, nbr, coef, bias_cv, z);
+                     p2r_stream(stream), p, ofs, x, W, nbr, coef, bias_cv, z, stats_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

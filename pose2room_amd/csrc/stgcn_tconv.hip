@@ -35,8 +35,8 @@ template <int TAPS>
 __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
     int n_seq, int T, int V, int F, int tiles_per_seq, int row_len, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ W,
-    const float *__restrict__ bias, float *__restrict__ out) {
-  extern __shared__ float hs[];   // [64][row_len], frames t0-HALO .. t0+F-1+HALO
+    const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ stats_partial) {
+  extern __shared__ float hs[];   // [64][row_len], frames t0-HALO .. t0+F-1+HALO; then [64][2] output statistics
   constexpr int HALO = (TAPS - 1) / 2;
   constexpr int NCH = TAPS == 1 ? TC_NPO / 64 : 8;   // 64-column chunks per tile row (tile + halo <= 64 * NCH)
 
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       }
     }
   };
+
+  float *rowstat = hs + TC_C * row_len;
+  if (tid < 2 * TC_C) rowstat[tid] = 0.f;
 
   int tile = blockIdx.x;
   if (tile < total_tiles) issue_loads(tile);
@@ -135,19 +138,35 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       }
     }
 
+    // Besides the store, the batch statistics of the output for the BatchNorm that follows (tcn.3 / the next
+    // MLP stage) are taken from the values just computed: lanes of a row by DPP, waves and tiles by LDS atomics.
 #pragma unroll
-    for (int i = 0; i < TC_NT; ++i) {
-      if (!valid[i]) continue;
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int q = 0; q < 4; ++q) {
+        const int row = 16 * m + 4 * g + q;
+        const float bv = bias ? bias[row] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = 16 * m + 4 * g + q;
-          og[(size_t)row * row_stride + colv[i]] = acc[i][m][q] + (bias ? bias[row] : 0.f);
+        for (int i = 0; i < TC_NT; ++i) {
+          if (!valid[i]) continue;
+          const float v = acc[i][m][q] + bv;
+          og[(size_t)row * row_stride + colv[i]] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
         }
-    }
+        if (stats_partial) {
+          s1 = p2r_row16_sum(s1);
+          s2 = p2r_row16_sum(s2);
+          if (r == 0) {
+            atomicAdd(rowstat + 2 * row, s1);
+            atomicAdd(rowstat + 2 * row + 1, s2);
+          }
+        }
+      }
     __syncthreads();   // every wave is done with the LDS tile before it is overwritten
   }
+  if (stats_partial && tid < 2 * TC_C) stats_partial[(size_t)blockIdx.x * 2 * TC_C + tid] = rowstat[tid];
 }
 
 // ---- weight gradient ------------------------------------------------------------------
@@ -160,7 +179,7 @@ template <int TAPS>
 __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
-    float *__restrict__ dw_partial) {
+    float *__restrict__ dw_partial, float *__restrict__ dbias_partial) {
   extern __shared__ float lds[];
   float *ds = lds;                       // [64][row_d]   dout tile, frames t0 .. t0+F-1
   float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-HALO .. t0+F-1+HALO
@@ -178,6 +197,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
   // 4-column step: keep them zero
   for (int e = tid; e < TC_C * (row_d + row_h); e += TC_THREADS) lds[e] = 0.f;
 
+  float bsum[TC_C / (TC_THREADS / 64)];    // per-lane share of the row sums of dout (bias gradient), rows wave, wave+8, ..
+#pragma unroll
+  for (int h = 0; h < TC_C / (TC_THREADS / 64); ++h) bsum[h] = 0.f;
   floatx4c acc[TAPS][2];
 #pragma unroll
   for (int p = 0; p < TAPS; ++p)
@@ -193,8 +215,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
     const long long col0 = (long long)(t0 - HALO) * V;
     __syncthreads();
-#pragma unroll 1
-    for (int c = wave; c < TC_C; c += TC_THREADS / 64) {
+#pragma unroll
+    for (int hh = 0; hh < TC_C / (TC_THREADS / 64); ++hh) {
+      const int c = wave + hh * (TC_THREADS / 64);
       const float *sx = xg + (size_t)c * row_stride;
       const float *sd = dg + (size_t)c * row_stride;
       const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
@@ -212,6 +235,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
         const int q = lane + 64 * i;
         vd[i] = q < ncols ? sd[q] : 0.f;
       }
+      bsum[hh] += (vd[0] + vd[1]) + (vd[2] + vd[3]);
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
@@ -238,6 +262,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
       }
     }
   }
+  if (dbias_partial) {
+#pragma unroll
+    for (int hh = 0; hh < TC_C / (TC_THREADS / 64); ++hh) {
+      float v = bsum[hh];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) dbias_partial[(size_t)blockIdx.x * TC_C + wave + hh * (TC_THREADS / 64)] = v;
+    }
+  }
   // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 32*mh + 16*m + row, ci = 16*nt + r
   float *outp = dw_partial + (size_t)blockIdx.x * TAPS * TC_C * TC_C;
 #pragma unroll
@@ -256,7 +289,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
 // (3,1) temporal convolution; taps = 1: a pointwise 64->64 convolution over the same layout.
 template <int TAPS>
 static int tconv_forward_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
-                                const float *W, const float *bias, float *out, void *stream) {
+                                const float *W, const float *bias, float *out, float *stats_partial,
+                                int *n_partials, void *stream) {
   constexpr int HALO = (TAPS - 1) / 2;
   int F = TC_NPO / V;
   if (F < 1) return P2R_EINVAL;
@@ -264,7 +298,7 @@ static int tconv_forward_launch(int N, int T, int V, const float *x, const float
   const int tiles_per_seq = p2r_cdiv(T, F);
   int row_len = (F + 2 * HALO) * V;
   if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
-  const size_t lds = (size_t)TC_C * row_len * sizeof(float);
+  const size_t lds = (size_t)TC_C * row_len * sizeof(float) + 2 * TC_C * sizeof(float);
   if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
@@ -276,24 +310,28 @@ static int tconv_forward_launch(int N, int T, int V, const float *x, const float
   const long long tiles = (long long)N * tiles_per_seq;
   if (tiles > 0x7fffffffLL) return P2R_EINVAL;
   const int blocks = (int)(tiles < 256 ? tiles : 256);      // persistent: one workgroup per CU
+  if (n_partials) *n_partials = blocks;
+  if (!out) return P2R_OK;                                  // size query
   hipLaunchKernelGGL(tconv_fused_kernel<TAPS>, dim3(blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
-                     F, tiles_per_seq, row_len, x, scale, shift, W, bias, out);
+                     F, tiles_per_seq, row_len, x, scale, shift, W, bias, out, stats_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
 
 extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const float *x, const float *scale,
                                        const float *shift, const float *W, const float *bias, float *out,
-                                       void *stream) {
+                                       float *stats_partial, int *n_partials, void *stream) {
   if (N < 0 || T <= 0 || V <= 0 || V > 128 || (taps != 1 && taps != 3)) return P2R_EINVAL;
+  if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
-  return taps == 3 ? tconv_forward_launch<3>(N, T, V, x, scale, shift, W, bias, out, stream)
-                   : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stream);
+  return taps == 3 ? tconv_forward_launch<3>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream)
+                   : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream);
 }
 
 template <int TAPS>
 static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
-                           const float *dout, int n_blocks, float *dw_partial, void *stream) {
+                           const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
+                           void *stream) {
   constexpr int HALO = (TAPS - 1) / 2;
   int row_d = TW_F * V + 3;                      // room for the last (partial) 4-column step
   while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
@@ -309,17 +347,18 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
     attr_set = true;
   }
   hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
-                     row_d, row_h, x, scale, shift, dout, dw_partial);
+                     row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
 
-// dw_partial [n_blocks][taps][64][64], summed over the leading axis by the caller.
+// dw_partial [n_blocks][taps][64][64] and (optional) dbias_partial [n_blocks][64] = row sums of dout,
+// both summed over the leading axis by the caller.
 extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,
                                            const float *shift, const float *dout, int n_blocks,
-                                           float *dw_partial, void *stream) {
+                                           float *dw_partial, float *dbias_partial, void *stream) {
   if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1 || (taps != 1 && taps != 3)) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  return taps == 3 ? tconv_dw_launch<3>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, stream)
-                   : tconv_dw_launch<1>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, stream);
+  return taps == 3 ? tconv_dw_launch<3>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
+                   : tconv_dw_launch<1>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
 }

@@ -32,6 +32,15 @@ def _stats(x):
     return mean, var, M
 
 
+def moments(part, M):
+    """(mean, biased var) in fp64 from kernel partials [P, C, 2] = (sum, sum of squares) over M elements
+    per channel (the graph-conv / temporal-conv kernels emit these from their epilogues)."""
+    tot = part.double().sum(0)
+    mean = tot[:, 0] / M
+    var = (tot[:, 1] / M - mean * mean).clamp_(min=0.0)
+    return mean, var, float(M)
+
+
 def _apply(x, scale, shift, res, relu):
     N, C, L = _rows(x)
     y = torch.empty_like(x)
@@ -105,9 +114,10 @@ def supported(x, bn):
     return x.is_cuda and x.dtype == torch.float32 and bn.affine and bn.track_running_stats and x.dim() >= 3
 
 
-def fused_bn_act(x, bn, res=None, relu=True):
+def fused_bn_act(x, bn, res=None, relu=True, stats=None):
+    """stats: optional kernel partials [P, C, 2] of x (see `moments`) replacing the statistics pass."""
     if bn.training:
-        mean64, var64, M = _stats(x.contiguous())
+        mean64, var64, M = _stats(x.contiguous()) if stats is None else moments(stats, x.numel() // x.shape[1])
         with torch.no_grad():
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
             bn.running_mean.mul_(1 - mom).add_(mom * mean64.float())

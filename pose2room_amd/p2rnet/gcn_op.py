@@ -42,31 +42,38 @@ class GraphTables:
         return self._dev[key]
 
 
-def _gcn_forward(x, W, nbr, coef, LkA, bias_cv, tables):
+def _gcn_forward(x, W, nbr, coef, LkA, bias_cv, tables, want_stats=False):
     N, C, T, V = x.shape
     z = torch.empty_like(x)
+    part = None
+    if want_stats:      # one (sum, sum of squares) row pair per workgroup = per (sample, tile of 384 // V frames)
+        frames = min(384 // V, T)
+        part = torch.empty((N * ((T + frames - 1) // frames), C, 2), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().p2r_stgcn_gcn_forward(
             N, T, V, tables.K, LkA, _lib.ptr(x), _lib.ptr(W), _lib.ptr(nbr), _lib.ptr(coef),
-            _lib.ptr(bias_cv), _lib.ptr(z), _lib.current_stream(x.device)), "stgcn_gcn_forward")
-    return z
+            _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part), _lib.current_stream(x.device)), "stgcn_gcn_forward")
+    return (z, part) if want_stats else z
 
 
 class _GraphConv(Function):
     @staticmethod
-    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables):
+    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
         x = x.contiguous()
         W = weight.contiguous()
-        z = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables)
+        out = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables,
+                           want_stats)
         ctx.save_for_backward(x, W, coef_c, coef_r)
         ctx.tables = tables
-        return z
+        if want_stats:
+            ctx.mark_non_differentiable(out[1])
+        return out
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, _dstats=None):
         x, W, coef_c, coef_r = ctx.saved_tensors
         tables = ctx.tables
         dev = x.device
@@ -117,7 +124,7 @@ class _GraphConv(Function):
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
-        return dx, dW, dcoef, None, dbias, None
+        return dx, dW, dcoef, None, dbias, None, None
 
 
 def supported(x, weight, A):
@@ -126,8 +133,10 @@ def supported(x, weight, A):
             and A.shape[1] <= 64)
 
 
-def graph_conv(x, weight, bias, Aeff, tables):
-    """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V)."""
+def graph_conv(x, weight, bias, Aeff, tables, want_stats=False):
+    """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
+    want_stats: also return the kernel's per-workgroup (sum, sum of squares) partials of z per channel
+    ([P,64,2], see bn_op.moments) -- the batch statistics of the BatchNorm that consumes z."""
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)
@@ -137,4 +146,4 @@ def graph_conv(x, weight, bias, Aeff, tables):
         bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
     else:
         bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
-    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables)
+    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats)

@@ -85,8 +85,12 @@ class STGCN(nn.Module):
             fused = tconv_op.supported_pointwise(z, s0.batchnorm, s1.conv) and \
                 tconv_op.supported_pointwise(z, s1.batchnorm, s2.conv)
             if fused:
-                z = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv)
-                z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv)
+                if s1.batchnorm.training:   # stage-1 statistics come out of the stage-0 kernel's epilogue
+                    z, zs = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv, want_stats=True)
+                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv, stats=zs)
+                else:
+                    z = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv)
+                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv)
                 return z.view(x.shape[0], 64, x.shape[2])
         for stage in seq:
             if x.is_cuda and hasattr(stage, 'batchnorm') and hasattr(stage, 'ReLU') and \

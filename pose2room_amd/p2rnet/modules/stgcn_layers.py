@@ -111,12 +111,15 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A):
+    def forward(self, x, A, want_stats=False):
+        """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
+        following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv)."""
         assert A.size(0) == self.kernel_size
         if self.tables is not None and self.fused:
             from .. import gcn_op
             if gcn_op.supported(x, self.conv.weight, A):
-                return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables), A
+                return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats), A
+        assert not want_stats
         y = self.conv(x)
         n, kc, t, v = y.size()
         y = y.view(n, self.kernel_size, kc // self.kernel_size, t, v)
@@ -163,10 +166,18 @@ class st_gcn_block(nn.Module):
 
     def forward(self, x, A):
         res = self.residual(x)
-        x, A = self.gcn(x, A)
         if self.fused_bn and x.is_cuda and self.tcn[4].p == 0:
-            from .. import bn_op
-            from .. import tconv_op
+            from .. import bn_op, gcn_op, tconv_op
+            # kernel epilogues hand the batch statistics to the BatchNorm that follows (train mode)
+            chain = (self.training and self.fused_tconv and self.gcn.tables is not None and self.gcn.fused
+                     and gcn_op.supported(x, self.gcn.conv.weight, A) and bn_op.supported(x, self.tcn[0])
+                     and tconv_op.supported(x, self.tcn[0], self.tcn[2]))
+            if chain:
+                (z, zstats), A = self.gcn(x, A, want_stats=True)
+                u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True)
+                res_t = res if torch.is_tensor(res) else None
+                return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats), A
+            x, A = self.gcn(x, A)
             if bn_op.supported(x, self.tcn[0]):
                 if self.fused_tconv and tconv_op.supported(x, self.tcn[0], self.tcn[2]):
                     u = tconv_op.bn_relu_tconv(x, self.tcn[0], self.tcn[2])       # tcn.0 + tcn.1 + tcn.2
@@ -175,5 +186,7 @@ class st_gcn_block(nn.Module):
                     u = self.tcn[2](h)                                             # temporal (3,1) conv
                 res_t = res if torch.is_tensor(res) else None
                 return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True), A    # tcn.3 (+res) + relu
+        else:
+            x, A = self.gcn(x, A)
         x = self.tcn(x) + res
         return self.relu(x), A

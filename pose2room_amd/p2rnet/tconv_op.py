@@ -11,6 +11,8 @@ The same op with a single tap serves the `cbr -> cbr -> c` embedding MLPs (stgcn
 BatchNorm + ReLU of stage i is folded into the pointwise 64->64 Conv1d of stage i+1
 (`bn_relu_pointwise`), and their 3->64 first layer has its own streaming kernel (`embed3`).
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -20,33 +22,43 @@ from . import bn_op
 _N_BLOCKS = 256
 
 
-def _tconv(x, scale, shift, W3, bias):
+def _tconv(x, scale, shift, W3, bias, want_stats=False):
     N, C, T, V = x.shape
     out = torch.empty_like(x)
+    lib = _lib.lib()
+    part = None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().p2r_stgcn_tconv_forward(N, T, V, W3.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
-                                                      _lib.ptr(W3), _lib.ptr(bias), _lib.ptr(out),
-                                                      _lib.current_stream(x.device)), "stgcn_tconv_forward")
-    return out
+        st = _lib.current_stream(x.device)
+        if want_stats:      # one (sum, sum of squares) partial per persistent workgroup: ask how many
+            n = ctypes.c_int(0)
+            _lib.check(lib.p2r_stgcn_tconv_forward(N, T, V, W3.shape[0], None, None, None, None, None, None, None,
+                                                   ctypes.byref(n), st), "stgcn_tconv_forward(size)")
+            part = torch.empty((n.value, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.p2r_stgcn_tconv_forward(N, T, V, W3.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift),
+                                               _lib.ptr(W3), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None, st),
+                   "stgcn_tconv_forward")
+    return (out, part) if want_stats else out
 
 
 class _BNReLUTConv(Function):
     @staticmethod
-    def forward(ctx, z, gamma, beta, mean, invstd, weight, bias, train):
+    def forward(ctx, z, gamma, beta, mean, invstd, weight, bias, train, want_stats=False):
         z = z.contiguous()
         scale = (gamma * invstd).contiguous()
         shift = (beta - mean * scale).contiguous()
         taps = weight.numel() // (64 * 64)
         W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
-        u = _tconv(z, scale, shift, W3, bias.contiguous() if bias is not None else None)
+        out = _tconv(z, scale, shift, W3, bias.contiguous() if bias is not None else None, want_stats)
         ctx.save_for_backward(z, gamma, mean, invstd, scale, shift, W3)
         ctx.train = train
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
-        return u
+        if want_stats:
+            ctx.mark_non_differentiable(out[1])
+        return out
 
     @staticmethod
-    def backward(ctx, du):
+    def backward(ctx, du, _dstats=None):
         z, gamma, mean, invstd, scale, shift, W3 = ctx.saved_tensors
         du = du.contiguous()
         N, C, T, V = z.shape
@@ -79,15 +91,14 @@ class _BNReLUTConv(Function):
                        "bn_bwd_apply")
             taps = W3.shape[0]
             part = torch.empty((_N_BLOCKS, taps, 64, 64), dtype=torch.float32, device=dev)
+            bpart = torch.empty((_N_BLOCKS, 64), dtype=torch.float32, device=dev) if ctx.has_bias else None
             _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
-                                                       _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), st),
+                                                       _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
                        "stgcn_tconv_weight_grad")
             dW = part.sum(0).permute(1, 2, 0).reshape(ctx.wshape).contiguous()
-            if ctx.has_bias:
-                sp = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
-                _lib.check(lib.p2r_bn_stats(N * C, L, _lib.ptr(du), _lib.ptr(sp), st), "bn_stats")
-                dbias = sp.view(N, C, 2)[:, :, 0].double().sum(0).float()
-        return dz, dgamma, dbeta, None, None, dW, dbias, None
+            if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
+                dbias = bpart.double().sum(0).float()
+        return dz, dgamma, dbeta, None, None, dW, dbias, None, None
 
 
 def supported(z, bn, conv):
@@ -147,9 +158,12 @@ def embed3(x, conv):
     return _Embed3.apply(x, conv.weight, conv.bias)
 
 
-def bn_relu_tconv(z, bn, conv):
+def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False):
+    """stats: kernel partials [P,64,2] of z from its producer (bn_op.moments) instead of a statistics pass;
+    want_stats: return (u, partials of u) for the BatchNorm that consumes u."""
     if bn.training:
-        mean64, var64, M = bn_op._stats(z.contiguous())
+        mean64, var64, M = bn_op._stats(z.contiguous()) if stats is None else \
+            bn_op.moments(stats, z.numel() // z.shape[1])
         with torch.no_grad():
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
             bn.running_mean.mul_(1 - mom).add_(mom * mean64.float())
@@ -157,6 +171,6 @@ def bn_relu_tconv(z, bn, conv):
             bn.num_batches_tracked += 1
         mean = mean64.float()
         invstd = torch.rsqrt(var64 + bn.eps).float()
-        return _BNReLUTConv.apply(z, bn.weight, bn.bias, mean, invstd, conv.weight, conv.bias, True)
+        return _BNReLUTConv.apply(z, bn.weight, bn.bias, mean, invstd, conv.weight, conv.bias, True, want_stats)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
-    return _BNReLUTConv.apply(z, bn.weight, bn.bias, bn.running_mean, invstd, conv.weight, conv.bias, False)
+    return _BNReLUTConv.apply(z, bn.weight, bn.bias, bn.running_mean, invstd, conv.weight, conv.bias, False, want_stats)

@@ -69,3 +69,26 @@ def test_block_fused_matches_unfused(dev):
     blk.gcn.fused = False
     y2, _ = blk(x.clone(), At)
     torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,T", [(2, 40), (1, 7), (3, 130)])
+def test_graph_conv_emitted_statistics(dev, N, T):
+    """want_stats: per-workgroup (sum, sum of squares) of z from the kernel epilogue == statistics of z."""
+    from pose2room_amd.p2rnet import gcn_op, bn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    torch.manual_seed(N + T)
+    x = torch.randn(N, 64, T, V, device=dev)
+    w = torch.randn(K * 64, 64, device=dev) / 8
+    b = torch.randn(K * 64, device=dev) * 0.1
+    Aeff = torch.tensor(A, dtype=torch.float32, device=dev) * (1 + 0.1 * torch.randn(K, V, V, device=dev))
+    z, part = gcn_op.graph_conv(x, w, b, Aeff, tables, want_stats=True)
+    assert torch.equal(z, gcn_op.graph_conv(x, w, b, Aeff, tables))
+    frames = min(384 // V, T)
+    assert part.shape == (N * ((T + frames - 1) // frames), 64, 2)
+    mean, var, _ = bn_op.moments(part, N * T * V)
+    zd = z.double()
+    torch.testing.assert_close(mean, zd.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(var, zd.var(dim=(0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-6)

@@ -109,3 +109,21 @@ def test_embed3(dev, B, L, bias):
     torch.testing.assert_close(conv.weight.grad.double(), ref.weight.grad, rtol=1e-4, atol=1e-4 * ref.weight.grad.abs().max().item())
     if bias:
         torch.testing.assert_close(conv.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-4 * ref.bias.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("N,T,V,taps", [(2, 40, 53, 3), (3, 9, 20, 1), (2, 130, 53, 3), (1, 300, 53, 1)])
+def test_kernel_emitted_statistics(dev, N, T, V, taps):
+    """The (sum, sum of squares) partials written by the conv epilogue equal the statistics of its output."""
+    from pose2room_amd.p2rnet import tconv_op, bn_op
+    torch.manual_seed(T)
+    x = torch.randn(N, 64, T, V, device=dev)
+    W = torch.randn(taps, 64, 64, device=dev) / 8
+    b = torch.randn(64, device=dev)
+    sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    out, part = tconv_op._tconv(x, sc, sh, W, b, want_stats=True)
+    assert part.dim() == 3 and part.shape[1:] == (64, 2)
+    assert torch.equal(out, tconv_op._tconv(x, sc, sh, W, b))          # same output with and without the statistics
+    mean, var, M = bn_op.moments(part, N * T * V)
+    o = out.double()
+    torch.testing.assert_close(mean, o.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(var, o.var(dim=(0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-6)

@@ -14,7 +14,7 @@ for Lval in (1, 2, 4, 8, 12):
     coef = torch.rand(ltot, V, device=dev)
     LkA = (ctypes.c_int * K)(*Lk)
     def call():
-        assert _lib.lib().p2r_stgcn_gcn_forward(N, T, V, K, LkA, _lib.ptr(x), _lib.ptr(W), _lib.ptr(nbr), _lib.ptr(coef), None, _lib.ptr(z), _lib.current_stream(dev)) == 0
+        assert _lib.lib().p2r_stgcn_gcn_forward(N, T, V, K, LkA, _lib.ptr(x), _lib.ptr(W), _lib.ptr(nbr), _lib.ptr(coef), None, _lib.ptr(z), None, _lib.current_stream(dev)) == 0
     for _ in range(2): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

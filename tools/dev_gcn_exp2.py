@@ -22,7 +22,7 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     def call():
-        assert lib.p2r_stgcn_gcn_forward(N, T, V, K, LkA, p(x), p(W), p(nb), p(coef), None, p(z), st) == 0
+        assert lib.p2r_stgcn_gcn_forward(N, T, V, K, LkA, p(x), p(W), p(nb), p(coef), None, p(z), None, st) == 0
     for _ in range(2): call()
     ts = []
     for rep in range(3):
@@ -33,7 +33,7 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
     zc = z.clone()
     LkR = (ctypes.c_int * K)(*Lk_r)
     def call_r():
-        assert lib.p2r_stgcn_gcn_forward(N, T, V, K, LkR, p(x), p(W), p(nb_r), p(coef_r), None, p(z), st) == 0
+        assert lib.p2r_stgcn_gcn_forward(N, T, V, K, LkR, p(x), p(W), p(nb_r), p(coef_r), None, p(z), None, st) == 0
     call_r(); tr = []
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
