@@ -108,7 +108,7 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   extern __shared__ float xs[];                       // [16 row groups][GC_ROW4] float4, then the int2 table
   float4 *xs4 = reinterpret_cast<float4 *>(xs);
   int2 *tbl = reinterpret_cast<int2 *>(xs + 16 * GC_ROW4 * 4);
-  float *rowstat = reinterpret_cast<float *>(tbl + ltot * p.V);   // [64][2] per-row (sum, sum of squares) of the output tile
+  float *rowstat = reinterpret_cast<float *>(tbl + ltot * p.V);   // [8 waves][64][2] per-row (sum, sum of squares) of the output tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -144,7 +144,6 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   }
   for (int e = tid; e < ltot * p.V; e += GC_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
-  if (tid < 2 * GC_C) rowstat[tid] = 0.f;
   __syncthreads();
 
   int colv[GC_NT16], fbase[GC_NT16], wj[GC_NT16];
@@ -240,13 +239,16 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float a = p2r_row16_sum(s1[m][q]), b = p2r_row16_sum(s2[m][q]);
-        if (r == 0) {
-          atomicAdd(rowstat + 2 * (16 * m + 4 * g + q), a);
-          atomicAdd(rowstat + 2 * (16 * m + 4 * g + q) + 1, b);
-        }
+        if (r == 0)     // one slot per wave: plain stores, no contention
+          *reinterpret_cast<float2 *>(rowstat + (wave * GC_C + 16 * m + 4 * g + q) * 2) = make_float2(a, b);
       }
     __syncthreads();
-    if (tid < 2 * GC_C) stats_partial[(size_t)blockIdx.x * 2 * GC_C + tid] = rowstat[tid];
+    if (tid < 2 * GC_C) {
+      float t = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < GC_THREADS / 64; ++w8) t += rowstat[w8 * 2 * GC_C + tid];
+      stats_partial[(size_t)blockIdx.x * 2 * GC_C + tid] = t;
+    }
   }
 }
 
@@ -276,7 +278,7 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
   }
   const long long blocks = (long long)N * p.tiles_per_seq;
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
-  const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2) + 2 * GC_C * sizeof(float);
+  const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2) + (GC_THREADS / 64) * 2 * GC_C * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
