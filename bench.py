@@ -64,11 +64,13 @@ GCN_TRAFFIC_BYTES = 1025853543   # profiles/r1_gcn_pmc_traffic.json: PMC FETCH_S
 
 def dominant_kernel_roofline(device, batch, frames):
     """The step's dominant kernel is gcn_fused_kernel (csrc/stgcn_gcn.hip): 12 launches per
-    step (6 blocks x forward + data gradient).  One launch at the bench shape is timed with
-    events on the stream it is launched on.  FLOPs per launch = what the kernel executes for
-    the reference's conv1x1 + graph einsum: dense 2*64*704 + sparse 2*64*971 per frame-joint
-    column (the reference's dense formulation of the same op is 2*64*704 + 2*64*53*11 per
-    column, reported as `reference_algorithmic_tflops`)."""
+    step = 6 blocks x (forward: column lists, bias table, statistics epilogue) + 6 x (data
+    gradient: transposed planes, row lists).  Both launch configurations are timed at the bench
+    shape with events on the stream they are launched on; `ms_per_launch` is their mean, which is
+    what rocprofv3's per-kernel average over a bench run shows.  FLOPs per launch = what the
+    kernel executes for the reference's conv1x1 + graph einsum: dense 2*64*704 + sparse 2*64*971
+    per frame-joint column (the reference's dense formulation of the same op is 2*64*704 +
+    2*64*53*11 per column, reported as `reference_algorithmic_tflops`)."""
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     from pose2room_amd.p2rnet import gcn_op, gcn_tables
     A = Graph().A
@@ -78,30 +80,39 @@ def dominant_kernel_roofline(device, batch, frames):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 64, frames, V, generator=g).to(device)
     W = (torch.randn(K * 64, 64, generator=g) / 8).to(device)
-    coef = gcn_tables.coefficients(torch.tensor(A, dtype=torch.float32, device=device), t['gidx_c']).contiguous()
+    At = torch.tensor(A, dtype=torch.float32, device=device)
+    coef_c = gcn_tables.coefficients(At, t['gidx_c']).contiguous()
+    coef_r = gcn_tables.coefficients(At, t['gidx_r']).contiguous()
     bias = torch.zeros(64, V, device=device)
-    fn = lambda: gcn_op._gcn_forward(x, W, t['nbr_c'], coef, tables.LkA_c, bias, tables)
-    for _ in range(3):
-        fn()
+    configs = {
+        'forward': lambda: gcn_op._gcn_forward(x, W, t['nbr_c'], coef_c, tables.LkA_c, bias, tables, True),
+        'data_gradient': lambda: gcn_op._gcn_forward(x, W, t['nbr_r'], coef_r, tables.LkA_r, None, tables),
+    }
     stream = torch.cuda.current_stream(device)
-    reps = 10
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        fn()
-    e1.record(stream)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    per = {}
+    for name, fn in configs.items():
+        for _ in range(3):
+            fn()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        per[name] = e0.elapsed_time(e1) / reps
+    ms = sum(per.values()) / len(per)
     cols = batch * frames * V
     nnz = int((A != 0).sum())
     flops = (2.0 * 64 * 64 * K + 2.0 * 64 * nnz / V) * cols
     ref_flops = (2.0 * 64 * 64 * K + 2.0 * 64 * V * K) * cols
     tf = flops / ms / 1e9
     scale = cols / float(32 * 1024 * 53)
-    return {'bound': 'mfma', 'kernel': 'gcn_fused_kernel (ST-GCN graph conv: forward and data gradient, 12 launches/step)',
+    return {'bound': 'mfma', 'kernel': 'gcn_fused_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
             'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': int(GCN_TRAFFIC_BYTES * scale),
-            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops,
+            'ms_per_launch': round(ms, 4), 'ms_forward': round(per['forward'], 4),
+            'ms_data_gradient': round(per['data_gradient'], 4), 'flops_per_launch': flops,
             'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
             'reference_algorithmic_tflops': round(ref_flops / ms / 1e9, 2)}
 
