@@ -125,6 +125,28 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
   float *zg = z + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
 
+  int colv[GC_NT16], fbase[GC_NT16], wj[GC_NT16];
+  bool valid[GC_NT16];
+#pragma unroll
+  for (int i = 0; i < GC_NT16; ++i) {
+    const int col = (wave * GC_NT16 + i) * 16 + r;
+    colv[i] = col;
+    valid[i] = col < ncols;
+    const int f = valid[i] ? col / p.V : 0;
+    wj[i] = valid[i] ? col - f * p.V : 0;
+    fbase[i] = f * p.V;
+  }
+
+  // accumulators start from the bias table (64 x V, L2 resident): these loads land while the tile is staged
+  floatx4_t acc[GC_NT16][4];
+#pragma unroll
+  for (int i = 0; i < GC_NT16; ++i)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[i][m][q] = bias_cv ? bias_cv[(16 * m + 4 * g + q) * p.V + wj[i]] : 0.f;
+
   // ---- stage the X tile (64 rows of `ncols` contiguous floats) and the (nbr, coef) table
 #pragma unroll 1
   for (int rg = wave; rg < GC_C / 4; rg += GC_THREADS / 64) {   // row group = 4 consecutive rows
@@ -145,24 +167,6 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
   for (int e = tid; e < ltot * p.V; e += GC_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
   __syncthreads();
-
-  int colv[GC_NT16], fbase[GC_NT16], wj[GC_NT16];
-  bool valid[GC_NT16];
-#pragma unroll
-  for (int i = 0; i < GC_NT16; ++i) {
-    const int col = (wave * GC_NT16 + i) * 16 + r;
-    colv[i] = col;
-    valid[i] = col < ncols;
-    const int f = valid[i] ? col / p.V : 0;
-    wj[i] = valid[i] ? col - f * p.V : 0;
-    fbase[i] = f * p.V;
-  }
-
-  floatx4_t acc[GC_NT16][4];
-#pragma unroll
-  for (int i = 0; i < GC_NT16; ++i)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[i][m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 
   const float4 *xg = xs4 + 4 * g * GC_ROW4;   // this lane group's 16 input channels = 4 row groups
 
@@ -223,8 +227,7 @@ __global__ __launch_bounds__(GC_THREADS, 2) void gcn_fused_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * m + 4 * g + q;
-        float v = acc[i][m][q];
-        if (bias_cv) v += bias_cv[row * p.V + wj[i]];
+        const float v = acc[i][m][q];
         zg[(size_t)row * row_stride + colv[i]] = v;
         s1[m][q] += v;
         s2[m][q] = fmaf(v, v, s2[m][q]);

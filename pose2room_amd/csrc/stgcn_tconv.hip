@@ -104,11 +104,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       valid[i] = col < ncols;
       base[i] = valid[i] ? col : 0;           // input column of plane p: base + p*V
     }
-    floatx4c acc[TC_NT][4];
+    floatx4c acc[TC_NT][4];              // start from the bias: its (L2-resident) loads overlap the first W wait
 #pragma unroll
-    for (int i = 0; i < TC_NT; ++i)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[i][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 4; ++q) {
+        const float bv = bias ? bias[16 * m + 4 * g + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TC_NT; ++i) acc[i][m][q] = bv;
+      }
 
     const float *hg = hs + g * 16 * row_len;
 #pragma unroll 1
@@ -145,12 +149,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * m + 4 * g + q;
-        const float bv = bias ? bias[row] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TC_NT; ++i) {
           if (!valid[i]) continue;
-          const float v = acc[i][m][q] + bv;
+          const float v = acc[i][m][q];
           og[(size_t)row * row_stride + colv[i]] = v;
           s1 += v;
           s2 = fmaf(v, v, s2);
