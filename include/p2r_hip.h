@@ -185,18 +185,6 @@ int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
                             const uint8_t *nbr, int n_blocks,
                             float *dcoef_partial, void *stream);
 
-/* data gradient AND adjacency gradient of the graph convolution in one dense pass
- * (H_k = W_k^T dZ is reduced against X for dcoef and aggregated over the row lists for
- * dX): dx (N,64,T,V) and dcoef_partial [n_blocks][sum Lc][V] from x, dz, Wt [K][64][64]
- * (transposed planes), the column lists (nbr_c, Lc_host) and the row lists (nbr_r, coef_r,
- * Lr_host).  4*V <= 256. */
-int p2r_stgcn_gcn_data_coef_grad(int N, int T, int V, int K, const int *Lc_host,
-                                 const int *Lr_host, const float *x, const float *dz,
-                                 const float *Wt, const uint8_t *nbr_c,
-                                 const uint8_t *nbr_r, const float *coef_r,
-                                 int n_blocks, float *dx, float *dcoef_partial,
-                                 void *stream);
-
 /* ---- BatchNorm + residual + ReLU of st_gcn_block (stgcn_layers.py:399-439) -------- */
 
 /* per-row partial sums for the batch statistics: x viewed as [rows = N*C][L] ->

@@ -796,253 +796,3 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
-
-// =============================================================================
-// Data gradient and adjacency gradient in ONE dense pass.
-//   H_k = W_k^T . dZ            (MFMA, per plane, no accumulation over k)
-//   dcoef[k][j][w] += sum_ci X[ci][(f, v_j)] * H_k[ci][(f, w)]        (column lists)
-//   dX[ci][(f, v)] += sum_j A_k[v][w_j] * H_k[ci][(f, w_j)]            (row lists)
-// Both consumers need H_k itself, so instead of running the graph-first kernel for dX and a
-// second dense pass for dcoef, the accumulator tile of plane k is (a) reduced against the
-// gathered X tile straight from registers and (b) parked in LDS (float4 of four consecutive
-// rows = one accumulator register quad) from where every lane aggregates its own dX columns
-// with plain FMAs.  Two barriers per plane; dZ B-operands stay in VGPRs for all planes.
-// Saves one of the four dense passes of a graph-conv forward+backward.
-// =============================================================================
-namespace {
-
-constexpr int BD_F = 4;              // frames per tile
-constexpr int BD_NT = 2;             // 16-column n-tiles per wave (8 waves x 2 x 16 = 256 >= 4*53)
-constexpr int BD_THREADS = 512;
-
-template <int L>
-__device__ __forceinline__ void bd_aggregate(float4 (&dxa)[4], const float4 *__restrict__ h4, int g,
-                                             const uint8_t *__restrict__ nrow, const float *__restrict__ crow,
-                                             int V, int row4, int fbase, bool live) {
-  int nb[L];
-  float cf[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    nb[j] = nrow[j * V];
-    cf[j] = live ? crow[j * V] : 0.f;
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const float4 *hr = h4 + (4 * m + g) * row4 + fbase;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const float4 hv = hr[nb[j]];
-      dxa[m].x = fmaf(cf[j], hv.x, dxa[m].x); dxa[m].y = fmaf(cf[j], hv.y, dxa[m].y);
-      dxa[m].z = fmaf(cf[j], hv.z, dxa[m].z); dxa[m].w = fmaf(cf[j], hv.w, dxa[m].w);
-    }
-  }
-}
-
-template <int L>
-__device__ __forceinline__ void bd_reduce(const floatx4_t (&h)[4], const float4 *__restrict__ xs4, int g,
-                                          const uint8_t *__restrict__ nrow, int V, int row4, int fbase,
-                                          float *__restrict__ dcs_row) {
-  int nb[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) nb[j] = nrow[j * V];
-  float part[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) part[j] = 0.f;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const float4 *xr = xs4 + (4 * m + g) * row4 + fbase;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const float4 xv = xr[nb[j]];
-      part[j] = fmaf(h[m][0], xv.x, part[j]); part[j] = fmaf(h[m][1], xv.y, part[j]);
-      part[j] = fmaf(h[m][2], xv.z, part[j]); part[j] = fmaf(h[m][3], xv.w, part[j]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < L; ++j) atomicAdd(dcs_row + j * V, part[j]);
-}
-
-#define P2R_SWITCH_L(L, CALL)                                                        \
-  switch (L) {                                                                       \
-    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;          \
-    case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break;          \
-    case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break;          \
-    case 10: CALL(10); break; case 11: CALL(11); break; default: CALL(12); break;    \
-  }
-
-struct BdParams {
-  int T, V, K, tiles_per_seq, row4;
-  int Lc[GC_MAXK], Lcofs[GC_MAXK];     // column lists (dcoef)
-  int Lr[GC_MAXK], Lrofs[GC_MAXK];     // row lists (dX)
-  int ltot_c, ltot_r;
-};
-
-__global__ __launch_bounds__(BD_THREADS, 2) void gcn_bwd_data_coef_kernel(
-    BdParams p, int n_seq, const float *__restrict__ x, const float *__restrict__ dz,
-    const float *__restrict__ Wt, const uint8_t *__restrict__ nbr_c, const uint8_t *__restrict__ nbr_r,
-    const float *__restrict__ coef_r, float *__restrict__ dx, float *__restrict__ dcoef_partial) {
-  extern __shared__ float lds[];
-  float4 *xs4 = reinterpret_cast<float4 *>(lds);                    // [16][row4] X tile (row-interleaved)
-  float4 *h4 = xs4 + 16 * p.row4;                                   // [16][row4] H_k staging
-  float *dcs = reinterpret_cast<float *>(h4 + 16 * p.row4);         // [ltot_c][V]
-  float *crs = dcs + p.ltot_c * p.V;                                // [ltot_r][V] coef of the row lists
-  uint8_t *ncs = reinterpret_cast<uint8_t *>(crs + p.ltot_r * p.V); // [ltot_c][V]
-  uint8_t *nrs = ncs + p.ltot_c * p.V;                              // [ltot_r][V]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, r = lane & 15;
-  for (int e = tid; e < p.ltot_c * p.V; e += BD_THREADS) { dcs[e] = 0.f; ncs[e] = nbr_c[e]; }
-  for (int e = tid; e < p.ltot_r * p.V; e += BD_THREADS) { crs[e] = coef_r[e]; nrs[e] = nbr_r[e]; }
-
-  const int total_tiles = n_seq * p.tiles_per_seq;
-  const size_t row_stride = (size_t)p.T * p.V;
-
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    const int seq = tile / p.tiles_per_seq;
-    const int t0 = (tile % p.tiles_per_seq) * BD_F;
-    const int ncols = min(BD_F, p.T - t0) * p.V;
-    const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    float *dxg = dx + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    __syncthreads();
-    // X tile, four consecutive rows -> one float4 per column
-#pragma unroll 1
-    for (int rg = wave; rg < GC_C / 4; rg += BD_THREADS / 64) {
-      float v[4][4];
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const float *src = xgm + (size_t)(4 * rg + h) * row_stride;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q = 64 * i + lane;
-          v[h][i] = q < ncols ? src[q] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = 64 * i + lane;
-        if (q < p.row4) xs4[rg * p.row4 + q] = make_float4(v[0][i], v[1][i], v[2][i], v[3][i]);
-      }
-    }
-
-    int colv[BD_NT], fbase[BD_NT], wj[BD_NT];
-    bool valid[BD_NT];
-    float bz[BD_NT][16];                 // dZ[c = 16g + s][col]
-    float4 dxa[BD_NT][4];
-#pragma unroll
-    for (int i = 0; i < BD_NT; ++i) {
-      const int col = (wave * BD_NT + i) * 16 + r;
-      colv[i] = col;
-      valid[i] = col < ncols;
-      const int f = valid[i] ? col / p.V : 0;
-      wj[i] = valid[i] ? col - f * p.V : 0;
-      fbase[i] = f * p.V;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + col] : 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) dxa[i][m] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-
-    for (int k = 0; k < p.K; ++k) {
-      float a[4][16];                     // Wt[k][ci = 16m + r][c = 16g .. 16g+15]
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float4 *wp = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 u = wp[q];
-          a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
-        }
-      }
-      const int Lc = p.Lc[k], Lr = p.Lr[k];
-#pragma unroll
-      for (int i = 0; i < BD_NT; ++i) {
-        floatx4_t h[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) h[m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bz[i][s], h[m], 0, 0, 0);
-        if (valid[i]) {
-          const uint8_t *nrow = ncs + p.Lcofs[k] * p.V + wj[i];
-          float *drow = dcs + p.Lcofs[k] * p.V + wj[i];
-#define P2R_CALL(LL) bd_reduce<LL>(h, xs4, g, nrow, p.V, p.row4, fbase[i], drow)
-          P2R_SWITCH_L(Lc, P2R_CALL)
-#undef P2R_CALL
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            h4[(4 * m + g) * p.row4 + colv[i]] = make_float4(h[m][0], h[m][1], h[m][2], h[m][3]);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < BD_NT; ++i) {
-        if (valid[i]) {
-          const uint8_t *nrow = nrs + p.Lrofs[k] * p.V + wj[i];
-          const float *crow = crs + p.Lrofs[k] * p.V + wj[i];
-#define P2R_CALL(LL) bd_aggregate<LL>(dxa[i], h4, g, nrow, crow, p.V, p.row4, fbase[i], true)
-          P2R_SWITCH_L(Lr, P2R_CALL)
-#undef P2R_CALL
-        }
-      }
-      __syncthreads();
-    }
-
-#pragma unroll
-    for (int i = 0; i < BD_NT; ++i) {
-      if (!valid[i]) continue;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const size_t rbase = (size_t)(16 * m + 4 * g) * row_stride + colv[i];
-        dxg[rbase] = dxa[i][m].x;
-        dxg[rbase + row_stride] = dxa[i][m].y;
-        dxg[rbase + 2 * row_stride] = dxa[i][m].z;
-        dxg[rbase + 3 * row_stride] = dxa[i][m].w;
-      }
-    }
-  }
-  __syncthreads();
-  float *outp = dcoef_partial + (size_t)blockIdx.x * p.ltot_c * p.V;
-  for (int q = tid; q < p.ltot_c * p.V; q += BD_THREADS) outp[q] = dcs[q];
-}
-
-}  // namespace
-
-// dx (N,64,T,V) and dcoef_partial [n_blocks][sum Lc][V] from x, dz, Wt [K][64(ci)][64(c)],
-// column lists (nbr_c, Lc_host) and row lists (nbr_r, coef_r, Lr_host).
-extern "C" int p2r_stgcn_gcn_data_coef_grad(int N, int T, int V, int K, const int *Lc_host, const int *Lr_host,
-                                            const float *x, const float *dz, const float *Wt,
-                                            const uint8_t *nbr_c, const uint8_t *nbr_r, const float *coef_r,
-                                            int n_blocks, float *dx, float *dcoef_partial, void *stream) {
-  if (N < 0 || T <= 0 || V <= 0 || BD_F * V > 256 || K <= 0 || K > GC_MAXK || n_blocks < 1) return P2R_EINVAL;
-  if (N == 0) return P2R_OK;
-  BdParams p;
-  p.T = T; p.V = V; p.K = K;
-  p.tiles_per_seq = p2r_cdiv(T, BD_F);
-  p.row4 = BD_F * V + 1;
-  int oc = 0, orr = 0;
-  for (int k = 0; k < K; ++k) {
-    if (Lc_host[k] < 1 || Lc_host[k] > GC_MAXL || Lr_host[k] < 1 || Lr_host[k] > GC_MAXL) return P2R_EINVAL;
-    p.Lc[k] = Lc_host[k]; p.Lcofs[k] = oc; oc += Lc_host[k];
-    p.Lr[k] = Lr_host[k]; p.Lrofs[k] = orr; orr += Lr_host[k];
-  }
-  p.ltot_c = oc; p.ltot_r = orr;
-  const size_t lds = 2 * (size_t)16 * p.row4 * sizeof(float4) + (size_t)(oc + orr) * V * sizeof(float) +
-                     (size_t)(oc + orr) * V + 16;
-  if (lds > 160 * 1024) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)gcn_bwd_data_coef_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gcn_bwd_data_coef_kernel, dim3(n_blocks), dim3(BD_THREADS), lds, p2r_stream(stream), p, N, x,
-                     dz, Wt, nbr_c, nbr_r, coef_r, dx, dcoef_partial);
-  P2R_LAUNCH_CHECK();
-  return P2R_OK;
-}

@@ -19,8 +19,6 @@ from .. import _lib
 from . import gcn_tables
 
 _N_BLOCKS = 256     # persistent workgroups of the reduction kernels (one per CU)
-_MERGED_BWD = False  # dX and dcoef from one dense pass (gcn_bwd_data_coef_kernel): correct, but at 4.6 ms vs
-                     # 1.9 + 2.6 ms for the two separate kernels not yet a win -- kept for the next round
 
 
 class GraphTables:
@@ -83,19 +81,7 @@ class _GraphConv(Function):
         K = tables.K
         Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
         dx = dW = dcoef = dbias = None
-        merged = ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and 4 * V <= 256 and _MERGED_BWD
-        if merged:
-            # one dense pass for both dX and the adjacency gradient (csrc: gcn_bwd_data_coef_kernel)
-            ltot = coef_c.shape[0]
-            dx = torch.empty_like(x)
-            part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(_lib.lib().p2r_stgcn_gcn_data_coef_grad(
-                    N, T, V, K, tables.LkA_c, tables.LkA_r, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wt),
-                    _lib.ptr(t['nbr_c']), _lib.ptr(t['nbr_r']), _lib.ptr(coef_r.contiguous()), _N_BLOCKS,
-                    _lib.ptr(dx), _lib.ptr(part), _lib.current_stream(dev)), "stgcn_gcn_data_coef_grad")
-            dcoef = part.sum(0)
-        elif ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
             dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
@@ -112,7 +98,7 @@ class _GraphConv(Function):
                 dW = part.sum(0).view(K * C, C)
                 if bpart is not None:
                     dbias = bpart.sum(0)                                   # (C, V)
-            if ctx.needs_input_grad[2] and not merged:
+            if ctx.needs_input_grad[2]:
                 ltot = coef_c.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_stgcn_gcn_coef_grad(
