@@ -209,7 +209,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[p][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  // Persistent loop with register prefetch: the global loads of the NEXT tile are issued right after the current
+  // tile has been written to LDS, so HBM latency and transfer hide under the MFMA phase (one workgroup per CU).
+  constexpr int NR = TC_C / (TC_THREADS / 64);     // rows per wave: wave, wave + 8, ...
+  float ph_[NR][NH], pd_[NR][4];
+  auto issue_loads = [&](int tile) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * TW_F;
     const int frames = min(TW_F, T - t0);
@@ -217,52 +221,72 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     const float *xg = x + (size_t)seq * TC_C * row_stride;
     const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
     const long long col0 = (long long)(t0 - HALO) * V;
-    __syncthreads();
 #pragma unroll
-    for (int hh = 0; hh < TC_C / (TC_THREADS / 64); ++hh) {
+    for (int hh = 0; hh < NR; ++hh) {
       const int c = wave + hh * (TC_THREADS / 64);
       const float *sx = xg + (size_t)c * row_stride;
       const float *sd = dg + (size_t)c * row_stride;
-      const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
-      float vh[NH], vd[4];
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
         const long long gc = col0 + q;
         const bool in = q < (frames + 2 * HALO) * V && gc >= 0 && gc < (long long)row_stride;
-        vh[i] = in ? sx[in ? gc : 0] : 0.f;
-        if (scale && in) vh[i] = fmaxf(fmaf(vh[i], sc, sh), 0.f);
+        ph_[hh][i] = in ? sx[in ? gc : 0] : __int_as_float(0x7fc00000);     // NaN marks "outside": becomes zero
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = lane + 64 * i;
-        vd[i] = q < ncols ? sd[q] : 0.f;
+        pd_[hh][i] = q < ncols ? sd[q] : 0.f;
       }
-      bsum[hh] += (vd[0] + vd[1]) + (vd[2] + vd[3]);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < total_tiles) issue_loads(tile);
+  for (; tile < total_tiles; tile += gridDim.x) {
+    __syncthreads();                                   // previous tile fully consumed
+#pragma unroll
+    for (int hh = 0; hh < NR; ++hh) {
+      const int c = wave + hh * (TC_THREADS / 64);
+      const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+      bsum[hh] += (pd_[hh][0] + pd_[hh][1]) + (pd_[hh][2] + pd_[hh][3]);
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
-        if (q < row_h) hs[c * row_h + q] = vh[i];
+        float v = ph_[hh][i];
+        if (v != v) v = 0.f;
+        else if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (q < row_h) hs[c * row_h + q] = v;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int q = lane + 64 * i;
-        if (q < row_d) ds[c * row_d + q] = vd[i];
+        if (q < row_d) ds[c * row_d + q] = pd_[hh][i];
       }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
 
     const float *drow = ds + (32 * mh + r) * row_d + g;       // + 16*m rows, + 4*s columns
     const float *hrow = hs + (16 * nt + r) * row_h + g;       // + p*V, + 4*s columns
     const int steps = (TW_F * V + 3) / 4;
+    // operands of step s+1 are read while the MFMAs of step s run (the rows are zero-padded past the last step)
+    float a0 = drow[0], a1 = drow[16 * row_d], b[TAPS];
+#pragma unroll
+    for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * V];
     for (int s = 0; s < steps; ++s) {
-      const float a0 = drow[4 * s], a1 = drow[16 * row_d + 4 * s];
+      const float na0 = drow[4 * s + 4], na1 = drow[16 * row_d + 4 * s + 4];
+      float nb[TAPS];
+#pragma unroll
+      for (int p = 0; p < TAPS; ++p) nb[p] = hrow[p * V + 4 * s + 4];
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) {
-        const float b = hrow[p * V + 4 * s];
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[p][1], 0, 0, 0);
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[p], acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[p], acc[p][1], 0, 0, 0);
       }
+      a0 = na0; a1 = na1;
+#pragma unroll
+      for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
     }
   }
   if (dbias_partial) {
@@ -336,9 +360,9 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
                            void *stream) {
   constexpr int HALO = (TAPS - 1) / 2;
-  int row_d = TW_F * V + 3;                      // room for the last (partial) 4-column step
+  int row_d = TW_F * V + 7;                      // room for the last (partial) 4-column step + one prefetched step
   while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
-  int row_h = (TW_F + 2 * HALO) * V + 3;
+  int row_h = (TW_F + 2 * HALO) * V + 7;
   while (row_h % 32 != 2) ++row_h;
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
   if (lds > 160 * 1024 || TW_F * V > 256 || (TW_F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;

@@ -20,3 +20,11 @@ for taps in (3, 1):
     W = torch.randn(taps, 64, 64, device=dev) / 8
     print(f'taps={taps} fwd(bn,bias,stats) {t(lambda: tconv_op._tconv(x, sc, sh, W, b, True)):.3f} ms   '
           f'data-grad(plain) {t(lambda: tconv_op._tconv(x, None, None, W, None)):.3f} ms')
+from pose2room_amd import _lib
+import ctypes
+for taps in (3, 1):
+    part = torch.empty(256, taps, 64, 64, device=dev); bp = torch.empty(256, 64, device=dev)
+    du = torch.randn(N, 64, T, V, device=dev)
+    st = _lib.current_stream(dev)
+    fn = lambda: _lib.check(_lib.lib().p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(du), 256, _lib.ptr(part), _lib.ptr(bp), st), 'wg')
+    print(f'taps={taps} weight_grad {t(fn):.3f} ms')
