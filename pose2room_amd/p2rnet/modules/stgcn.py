@@ -63,7 +63,11 @@ class STGCN(nn.Module):
             return torch.sort(inds, dim=1)[0].to(device)
         if self.seed_sampling == 'uniform':   # equal arc length along the hip trajectory
             step = torch.norm(torch.diff(hip, dim=1), dim=2)
-            cum = torch.cumsum(torch.cat([torch.zeros(size=(n_batch, 1)).to(device), step], dim=1), dim=1)
+            # Arc length accumulated in float64 and rounded once per prefix -- exactly what torch's CPU cumsum
+            # of float32 does (the reference's CPU result), whereas a float32 parallel scan on the GPU rounds
+            # the prefixes of a plateau (repeated frames: step == 0) differently and breaks their exact ties.
+            cum = torch.cumsum(torch.cat([torch.zeros(size=(n_batch, 1)).to(device), step], dim=1).double(),
+                               dim=1).float()
             stride = cum[:, -1] / (self.n_seeds - 1)
             target = stride.unsqueeze(-1) * torch.arange(self.n_seeds, dtype=torch.float).to(device)
             return torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)
