@@ -212,6 +212,20 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
                      int relu, const float *mscale, const float *mshift,
                      float *dx, float *dres, void *stream);
 
+/* statistics finalisation (one small launch instead of a dozen elementwise ones): partial [P][C][2] =
+ * (sum, sum of squares) rows from p2r_bn_stats (P = N) or from the conv epilogues' stats_partial,
+ * M = elements per channel.  out [4][C] = mean, invstd = 1/sqrt(var + eps), scale = gamma*invstd,
+ * shift = beta - mean*scale (biased variance, fp64 combination).  momentum >= 0 also updates
+ * running_mean / running_var in place as nn.BatchNorm does (unbiased variance); momentum < 0 leaves
+ * them untouched (they may be NULL then). */
+int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma,
+                    const float *beta, double eps, double momentum, float *running_mean,
+                    float *running_var, float *out, void *stream);
+
+/* backward counterpart: partial [P][C][2] = (sum g, sum g*xhat) rows -> out [4][C] =
+ * sum g (= dbeta), sum g*xhat (= dgamma), (sum g)/M, (sum g*xhat)/M. */
+int p2r_bn_bwd_finalize(int P, int C, const float *partial, double M, float *out, void *stream);
+
 /* ---- temporal (3,1) convolution of st_gcn_block, BatchNorm+ReLU fused on the input ---- */
 
 /* replaces tcn.0-tcn.2 (stgcn_layers.py:399-411): out[n,c,t,w] = bias[c] + sum_p sum_ci

@@ -272,6 +272,98 @@ extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const floa
   return P2R_OK;
 }
 
+// ---- statistics finalisation: kernel partials -> per-channel constants, one tiny launch -------------
+// partial [P][C][2] (bn_stats rows (n, c), or the conv epilogues' per-workgroup rows); one workgroup per
+// channel sums its P pairs in fp64.
+namespace {
+
+constexpr int FIN_THREADS = 256;
+
+__device__ __forceinline__ void fin_block_sum(double &a, double &b) {
+  __shared__ double sa[FIN_THREADS / 64], sb[FIN_THREADS / 64];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int i = 0; i < FIN_THREADS / 64; ++i) { a += sa[i]; b += sb[i]; }
+}
+
+// out [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running statistics updated in
+// place with `momentum` (unbiased variance, like nn.BatchNorm) unless momentum < 0.
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(int P, int C, const float2 *__restrict__ partial,
+                                                                  double M, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, double eps,
+                                                                  double momentum, float *__restrict__ running_mean,
+                                                                  float *__restrict__ running_var,
+                                                                  float *__restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
+    const float2 v = partial[(size_t)p * C + c];
+    s += (double)v.x; q += (double)v.y;
+  }
+  fin_block_sum(s, q);
+  if (threadIdx.x == 0) {
+    const double mean = s / M;
+    double var = q / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mean, invstd_f = (float)(1.0 / sqrt(var + eps));
+    const float scale = gamma[c] * invstd_f;
+    out[c] = mean_f;
+    out[C + c] = invstd_f;
+    out[2 * C + c] = scale;
+    out[3 * C + c] = beta[c] - mean_f * scale;
+    if (momentum >= 0.0) {
+      const float mom = (float)momentum;
+      const double unbiased = var * (M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0));
+      running_mean[c] = running_mean[c] * (1.f - mom) + mom * mean_f;
+      running_var[c] = running_var[c] * (1.f - mom) + mom * (float)unbiased;
+    }
+  }
+}
+
+// out [4][C] = sum g, sum g*xhat, (sum g)/M, (sum g*xhat)/M
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(int P, int C, const float2 *__restrict__ partial,
+                                                                      double M, float *__restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
+    const float2 v = partial[(size_t)p * C + c];
+    s += (double)v.x; q += (double)v.y;
+  }
+  fin_block_sum(s, q);
+  if (threadIdx.x == 0) {
+    out[c] = (float)s;
+    out[C + c] = (float)q;
+    out[2 * C + c] = (float)(s / M);
+    out[3 * C + c] = (float)(q / M);
+  }
+}
+
+}  // namespace
+
+extern "C" int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma, const float *beta,
+                               double eps, double momentum, float *running_mean, float *running_var, float *out,
+                               void *stream) {
+  if (P <= 0 || C <= 0 || M <= 0.0) return P2R_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, p2r_stream(stream), P, C,
+                     reinterpret_cast<const float2 *>(partial), M, gamma, beta, eps, momentum, running_mean,
+                     running_var, out);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+extern "C" int p2r_bn_bwd_finalize(int P, int C, const float *partial, double M, float *out, void *stream) {
+  if (P <= 0 || C <= 0 || M <= 0.0) return P2R_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, p2r_stream(stream), P, C,
+                     reinterpret_cast<const float2 *>(partial), M, out);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
 // ---- per-(channel, joint) sums over samples and frames -------------------------------
 // out_partial[row][w] = sum_t x[row][t*V + w]   (row = (n, c)); the caller sums over n.
 // Used for the gradient of the graph-conv bias term (a (C, V) table).

@@ -6,6 +6,8 @@ mode (batch statistics, running-stat update with the module's momentum, unbiased
 variance) and eval mode (running statistics), differentiable w.r.t. x, bn.weight, bn.bias
 and res.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -18,18 +20,51 @@ def _rows(x):
     return N, C, L
 
 
-def _stats(x):
-    """per-channel (mean, biased var) in fp64 from one HBM pass."""
+def _stats_partial(x):
+    """per-(sample, channel) (sum, sum of squares) rows [N, C, 2] from one HBM pass."""
     N, C, L = _rows(x)
-    part = torch.empty((N * C, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().p2r_bn_stats(N * C, L, _lib.ptr(x), _lib.ptr(part), _lib.current_stream(x.device)),
                    "bn_stats")
-    tot = part.view(N, C, 2).double().sum(0)
-    M = float(N * L)
-    mean = tot[:, 0] / M
-    var = (tot[:, 1] / M - mean * mean).clamp_(min=0.0)
-    return mean, var, M
+    return part
+
+
+def _stats(x):
+    """per-channel (mean, biased var) in fp64 from one HBM pass."""
+    N, C, L = _rows(x)
+    return moments(_stats_partial(x), N * L)
+
+
+def finalize(part, M, bn):
+    """Kernel partials [P, C, 2] -> fin [4, C] = (mean, invstd, scale, shift) of BatchNorm module `bn` in one
+    launch, which also applies the running-statistics update (momentum, unbiased variance) in place."""
+    part = part.contiguous()
+    P, C = part.shape[0], part.shape[1]
+    fin = torch.empty((4, C), dtype=torch.float32, device=part.device)
+    if bn.momentum is None:      # cumulative moving average: the factor depends on the step counter
+        mom = 1.0 / float(bn.num_batches_tracked + 1)
+    else:
+        mom = float(bn.momentum)
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.lib().p2r_bn_finalize(P, C, _lib.ptr(part), ctypes.c_double(float(M)), _lib.ptr(bn.weight),
+                                              _lib.ptr(bn.bias), ctypes.c_double(float(bn.eps)), ctypes.c_double(mom),
+                                              _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(fin),
+                                              _lib.current_stream(part.device)), "bn_finalize")
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return fin
+
+
+def bwd_finalize(part, M):
+    """Backward partials [P, C, 2] = (sum g, sum g*xhat) -> [4, C] = (dbeta, dgamma, m1, m2)."""
+    part = part.contiguous()
+    P, C = part.shape[0], part.shape[1]
+    out = torch.empty((4, C), dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.lib().p2r_bn_bwd_finalize(P, C, _lib.ptr(part), ctypes.c_double(float(M)), _lib.ptr(out),
+                                                  _lib.current_stream(part.device)), "bn_bwd_finalize")
+    return out
 
 
 def moments(part, M):
@@ -51,45 +86,40 @@ def _apply(x, scale, shift, res, relu):
 
 
 class _FusedBNAct(Function):
+    """Train-mode BatchNorm (+res) (+ReLU).  `fin` [4, C] = (mean, invstd, scale, shift) from `finalize`."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, res, mean, invstd, relu):
+    def forward(ctx, x, weight, bias, res, fin, relu):
         x = x.contiguous()
         res_c = res.contiguous() if res is not None else None
-        scale = (weight * invstd).contiguous()
-        shift = (bias - mean * scale).contiguous()
-        y = _apply(x, scale, shift, res_c, relu)
-        ctx.save_for_backward(x, y, weight, mean, invstd)
+        y = _apply(x, fin[2], fin[3], res_c, relu)
+        ctx.save_for_backward(x, y, fin)
         ctx.relu = relu
         ctx.has_res = res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, fin = ctx.saved_tensors
+        mean, invstd, kscale = fin[0], fin[1], fin[2]
         dy = dy.contiguous()
         N, C, L = _rows(x)
         dev = x.device
         lib = _lib.lib()
-        part = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+        part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
                                              _lib.ptr(invstd), int(ctx.relu), None, None, _lib.ptr(part),
                                              _lib.current_stream(dev)), "bn_bwd_reduce")
-        tot = part.view(N, C, 2).double().sum(0)
-        dbias = tot[:, 0].float()
-        dweight = tot[:, 1].float()
-        M = float(N * L)
-        m1 = (tot[:, 0] / M).float().contiguous()
-        m2 = (tot[:, 1] / M).float().contiguous()
-        kscale = (weight * invstd).contiguous()
+        tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
-                                            _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(m1), _lib.ptr(m2),
+                                            _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
                                             int(ctx.relu), None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
-        return dx, dweight, dbias, dres, None, None, None
+        return dx, tot[1], tot[0], dres, None, None
 
 
 class _EvalBNAct(Function):
@@ -117,16 +147,9 @@ def supported(x, bn):
 def fused_bn_act(x, bn, res=None, relu=True, stats=None):
     """stats: optional kernel partials [P, C, 2] of x (see `moments`) replacing the statistics pass."""
     if bn.training:
-        mean64, var64, M = _stats(x.contiguous()) if stats is None else moments(stats, x.numel() // x.shape[1])
-        with torch.no_grad():
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-            bn.running_mean.mul_(1 - mom).add_(mom * mean64.float())
-            unbiased = var64 * (M / max(M - 1.0, 1.0))
-            bn.running_var.mul_(1 - mom).add_(mom * unbiased.float())
-            bn.num_batches_tracked += 1
-        mean = mean64.float()
-        invstd = torch.rsqrt(var64 + bn.eps).float()
-        return _FusedBNAct.apply(x, bn.weight, bn.bias, res, mean, invstd, relu)
+        part = _stats_partial(x.contiguous()) if stats is None else stats
+        fin = finalize(part, x.numel() // x.shape[1], bn)
+        return _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     shift = bn.bias - bn.running_mean * scale

@@ -41,15 +41,16 @@ def _tconv(x, scale, shift, W3, bias, want_stats=False):
 
 
 class _BNReLUTConv(Function):
+    """`fin` [4, 64] = (mean, invstd, scale, shift) of the BatchNorm in front (bn_op.finalize, or the eval-mode
+    constants)."""
+
     @staticmethod
-    def forward(ctx, z, gamma, beta, mean, invstd, weight, bias, train, want_stats=False):
+    def forward(ctx, z, gamma, beta, fin, weight, bias, train, want_stats=False):
         z = z.contiguous()
-        scale = (gamma * invstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
         taps = weight.numel() // (64 * 64)
         W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
-        out = _tconv(z, scale, shift, W3, bias.contiguous() if bias is not None else None, want_stats)
-        ctx.save_for_backward(z, gamma, mean, invstd, scale, shift, W3)
+        out = _tconv(z, fin[2], fin[3], W3, bias.contiguous() if bias is not None else None, want_stats)
+        ctx.save_for_backward(z, fin, W3)
         ctx.train = train
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
@@ -59,7 +60,8 @@ class _BNReLUTConv(Function):
 
     @staticmethod
     def backward(ctx, du, _dstats=None):
-        z, gamma, mean, invstd, scale, shift, W3 = ctx.saved_tensors
+        z, fin, W3 = ctx.saved_tensors
+        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         du = du.contiguous()
         N, C, T, V = z.shape
         L = T * V
@@ -72,15 +74,12 @@ class _BNReLUTConv(Function):
         dz = dgamma = dbeta = dW = dbias = None
         with torch.cuda.device(dev):
             if ctx.train:
-                part = torch.empty((N * C, 2), dtype=torch.float32, device=dev)
+                part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
                                                  _lib.ptr(invstd), 2, _lib.ptr(scale), _lib.ptr(shift),
                                                  _lib.ptr(part), st), "bn_bwd_reduce")
-                tot = part.view(N, C, 2).double().sum(0)
-                dbeta, dgamma = tot[:, 0].float(), tot[:, 1].float()
-                M = float(N * L)
-                m1 = (tot[:, 0] / M).float().contiguous()
-                m2 = (tot[:, 1] / M).float().contiguous()
+                tot = bn_op.bwd_finalize(part, N * L)              # (dbeta, dgamma, m1, m2)
+                dbeta, dgamma, m1, m2 = tot[0], tot[1], tot[2], tot[3]
             else:   # eval: statistics are constants, dz = scale * g
                 m1 = torch.zeros(C, device=dev)
                 m2 = torch.zeros(C, device=dev)
@@ -98,7 +97,7 @@ class _BNReLUTConv(Function):
             dW = part.sum(0).permute(1, 2, 0).reshape(ctx.wshape).contiguous()
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
                 dbias = bpart.double().sum(0).float()
-        return dz, dgamma, dbeta, None, None, dW, dbias, None, None
+        return dz, dgamma, dbeta, None, dW, dbias, None, None
 
 
 def supported(z, bn, conv):
@@ -162,15 +161,10 @@ def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False):
     """stats: kernel partials [P,64,2] of z from its producer (bn_op.moments) instead of a statistics pass;
     want_stats: return (u, partials of u) for the BatchNorm that consumes u."""
     if bn.training:
-        mean64, var64, M = bn_op._stats(z.contiguous()) if stats is None else \
-            bn_op.moments(stats, z.numel() // z.shape[1])
-        with torch.no_grad():
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-            bn.running_mean.mul_(1 - mom).add_(mom * mean64.float())
-            bn.running_var.mul_(1 - mom).add_(mom * (var64 * (M / max(M - 1.0, 1.0))).float())
-            bn.num_batches_tracked += 1
-        mean = mean64.float()
-        invstd = torch.rsqrt(var64 + bn.eps).float()
-        return _BNReLUTConv.apply(z, bn.weight, bn.bias, mean, invstd, conv.weight, conv.bias, True, want_stats)
+        part = bn_op._stats_partial(z.contiguous()) if stats is None else stats
+        fin = bn_op.finalize(part, z.numel() // z.shape[1], bn)     # also updates the running statistics
+        return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
-    return _BNReLUTConv.apply(z, bn.weight, bn.bias, bn.running_mean, invstd, conv.weight, conv.bias, False, want_stats)
+    scale = bn.weight * invstd
+    fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale])
+    return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, False, want_stats)
