@@ -38,6 +38,15 @@ def reduce_dict(input_dict, average=True):
         return {k: v for k, v in zip(names, values)}
 
 
+def _scalars(loss_dict):
+    """{name: python float} like the reference's `{k: v.item()}` (models/training.py:41-42), but with one
+    device->host transfer for the whole dict instead of one synchronisation per entry."""
+    names = list(loss_dict.keys())
+    with torch.no_grad():     # float32 -> float64 is exact, so the numbers equal `.item()` of each entry
+        vals = torch.stack([loss_dict[k].detach().double() for k in names]).tolist()
+    return dict(zip(names, vals))
+
+
 def load_optimizer(config, net):
     """AdamW with the yaml's Adam hyper-parameters (models/optimizers.py:90-94: the
     reference builds AdamW for `method: Adam`)."""
@@ -80,12 +89,10 @@ class Trainer(object):
             if max_norm > 0:
                 torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm)
             self.optimizer.step()
-        loss_reduced = reduce_dict(loss)
-        return {k: v.item() for k, v in loss_reduced.items()}
+        return _scalars(reduce_dict(loss))
 
     def eval_step(self, data):
         data = self.to_device(data)
         est_data = self.net(data)
         loss = self.net.module.loss(est_data, data)
-        loss_reduced = reduce_dict(loss)
-        return {k: v.item() for k, v in loss_reduced.items()}
+        return _scalars(reduce_dict(loss))
