@@ -59,7 +59,7 @@ def build_trainer(device, frames, world):
     return Trainer(cfg, net, load_optimizer(cfg.config, net), device), cfg
 
 
-GCN_TRAFFIC_BYTES = 1025853543   # profiles/r1_gcn_pmc_traffic.json: PMC FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE
+GCN_TRAFFIC_BYTES = 992719091    # profiles/r1_gcn_pmc_traffic.json (tools/pmc_traffic.sh): FETCH_SIZE (x2.0, calibrated) + WRITE_SIZE per launch
 
 
 def dominant_kernel_roofline(device, batch, frames):
