@@ -80,7 +80,9 @@ class BoxNetDetectionLoss(BaseLoss):
         seed_gt_votes = torch.gather(gt_data['vote_label'][:, :, j0], 1,
                                      seed_inds.view(batch_size, num_seed, 1).repeat(1, 1, 3 * GT_VOTE_FACTOR))
         seed_gt_votes = seed_gt_votes.view(batch_size, num_seed, GT_VOTE_FACTOR, 3)
-        seed_gt_votes = est_data['seed_skeleton'][:, :, [j0]] + seed_gt_votes
+        # slice, not the reference's list index `[:, :, [j0]]`: a list index uploads an index tensor from the host,
+        # which synchronises the stream in the middle of the step
+        seed_gt_votes = est_data['seed_skeleton'][:, :, j0:j0 + 1] + seed_gt_votes
 
         # which of the 3 GT votes is closest to any joint of the seed skeleton
         _, _, dist2, ind2 = nn_distance(seed_gt_votes.view(batch_size * num_seed, GT_VOTE_FACTOR, 3),
@@ -103,11 +105,12 @@ class BoxNetDetectionLoss(BaseLoss):
 
         B, K = aggregated_vote_xyz.shape[0], aggregated_vote_xyz.shape[1]
         euclidean_dist1 = torch.sqrt(dist1 + 1e-6)
-        objectness_label = torch.zeros((B, K), dtype=torch.long).to(self.device)
-        objectness_mask = torch.zeros((B, K)).to(self.device)
-        objectness_label[euclidean_dist1 < NEAR_THRESHOLD] = 1
-        objectness_mask[euclidean_dist1 < NEAR_THRESHOLD] = 1
-        objectness_mask[euclidean_dist1 > FAR_THRESHOLD] = 1
+        # the reference fills host-created zero tensors through boolean-mask assignment (loss.py:141-145): three
+        # device->host synchronisations (mask -> nonzero) and two pageable uploads in the middle of the step; the
+        # same values as pure device expressions keep the step asynchronous
+        near = euclidean_dist1 < NEAR_THRESHOLD
+        objectness_label = near.long()
+        objectness_mask = (near | (euclidean_dist1 > FAR_THRESHOLD)).float()
 
         objectness_loss = self.objectness_criterion(est_data['objectness_scores'].transpose(2, 1), objectness_label)
         objectness_loss = torch.sum(objectness_loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
@@ -125,7 +128,7 @@ class BoxNetDetectionLoss(BaseLoss):
             10 * heading_loss + sem_cls_loss
 
         total = objectness_label.shape[0] * objectness_label.shape[1]
-        pos_ratio = torch.sum(objectness_label.float().to(self.device)) / float(total)
+        pos_ratio = torch.sum(objectness_label.float()) / float(total)
         neg_ratio = torch.sum(objectness_mask.float()) / float(total) - pos_ratio
         obj_pred_val = torch.argmax(est_data['objectness_scores'], 2)
         obj_acc = torch.sum((obj_pred_val == objectness_label.long()).float() * objectness_mask) / (

@@ -66,10 +66,10 @@ class STGCN(nn.Module):
             # Arc length accumulated in float64 and rounded once per prefix -- exactly what torch's CPU cumsum
             # of float32 does (the reference's CPU result), whereas a float32 parallel scan on the GPU rounds
             # the prefixes of a plateau (repeated frames: step == 0) differently and breaks their exact ties.
-            cum = torch.cumsum(torch.cat([torch.zeros(size=(n_batch, 1)).to(device), step], dim=1).double(),
+            cum = torch.cumsum(torch.cat([torch.zeros(size=(n_batch, 1), device=device), step], dim=1).double(),
                                dim=1).float()
             stride = cum[:, -1] / (self.n_seeds - 1)
-            target = stride.unsqueeze(-1) * torch.arange(self.n_seeds, dtype=torch.float).to(device)
+            target = stride.unsqueeze(-1) * torch.arange(self.n_seeds, dtype=torch.float, device=device)
             return torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)
         raise NotImplementedError
 
@@ -117,7 +117,7 @@ class STGCN(nn.Module):
         offs = hip[:, win] - hip.unsqueeze(2)                                  # (B,T,knn,3)
         pe = self._mlp(self.pos_embed, offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2).contiguous(), self.knn)
         pe = pe.view(n_batch, -1, n_frames, self.knn).mean(dim=3)             # (B,64,T)
-        rel = input_joints - input_joints[:, :, [self.origin_joint_id]]
+        rel = input_joints - input_joints[:, :, self.origin_joint_id:self.origin_joint_id + 1]
         sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2).contiguous(), n_joints)
         return sk.view(n_batch, -1, n_frames, n_joints) + pe.unsqueeze(-1)
 
