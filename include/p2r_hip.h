@@ -165,24 +165,33 @@ int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
                           const float *coef, const float *bias_cv, float *z,
                           float *stats_partial, void *stream);
 
-/* weight gradient of the above (autograd of stgcn_layers.py:62-65):
- * dw_partial [n_blocks][K][64][64], to be summed over the leading axis by the
- * caller (deterministic).  K <= 12, V <= 64.  colsum_partial, when not NULL,
- * receives [n_blocks][64][V] partial sums of dz over samples and frames (the
- * gradient of the bias table bias_cv of the forward), read from the same tiles. */
+/* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
+ * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over
+ * all columns of dz[a][col] * G_k[b][col] at [k][a][b], to be summed over the leading axis by the
+ * caller (deterministic).  K <= 12, V <= 64.  Called as (x, dz, column lists) this is dW_k[c][ci];
+ * called as (dz, x, row lists) it is dW_k transposed ([k][ci][c]) -- the same numbers with the
+ * aggregation on the gradient side, where the row lists leave more (plane, joint-group) units
+ * empty to skip.  colsum_partial, when not NULL, receives [n_blocks][64][V] partial sums over
+ * samples and frames of the `dz` argument (colsum_of_x = 0) or of the `x` argument
+ * (colsum_of_x != 0): the gradient of the bias table bias_cv, read from the same tiles. */
 int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host,
                               const float *x, const float *dz,
                               const uint8_t *nbr, const float *coef,
                               int n_blocks, float *dw_partial, float *colsum_partial,
-                              void *stream);
+                              int colsum_of_x, void *stream);
 
 /* gradient w.r.t. the non-zero adjacency entries (reaches edge_importance,
- * stgcn.py:134): Wt [K][64][64] = transposed planes, nbr = the column lists;
- * dcoef_partial [n_blocks][sum_k Lk][V], summed over the leading axis by the
- * caller. */
+ * stgcn.py:134): H_k = Wt_k^T . dz on MFMA, reduced against x gathered through the lists:
+ * dcoef_partial [n_blocks][sum_k Lk][V] (entry (k, j, w) pairs column w of dz with the j-th
+ * listed column of x), summed over the leading axis by the caller.  Wt [K][64][64] = the
+ * planes with rows = the reduce index of dz's channels.  Two equivalent ways to call it:
+ * (x, dz, transposed planes, column lists) or (dz, x, forward planes, row lists) -- the
+ * second one lets whole (plane, 16-column) units be skipped, the row lists being emptier.
+ * coef (the list's coefficient table, or NULL) is only used to tell real slots from padding;
+ * without it every slot 0 counts as real and nothing is skipped. */
 int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
                             const float *x, const float *dz, const float *Wt,
-                            const uint8_t *nbr, int n_blocks,
+                            const uint8_t *nbr, const float *coef, int n_blocks,
                             float *dcoef_partial, void *stream);
 
 /* ---- BatchNorm + residual + ReLU of st_gcn_block (stgcn_layers.py:399-439) -------- */

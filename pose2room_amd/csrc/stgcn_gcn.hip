@@ -357,7 +357,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
                                                                const uint8_t *__restrict__ nbr,
                                                                const float *__restrict__ coef,
                                                                float *__restrict__ dw_partial,
-                                                               float *__restrict__ colsum_partial) {
+                                                               float *__restrict__ colsum_partial,
+                                                               int colsum_of_x) {
   extern __shared__ float lds[];
   float *dzs = lds;                                   // [64][row_len]
   float *xs = lds + GC_C * row_len;                   // [64][row_len]
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
         const int idx = tid + DW_THREADS * n;
         if (idx < GC_C * p.V) {
           const int c = idx / p.V, w = idx - c * p.V;
-          const float *dp = dzs + c * row_len + w;
+          const float *dp = (colsum_of_x ? xs : dzs) + c * row_len + w;
           float sum = 0.f;
 #pragma unroll
           for (int f = 0; f < DW_F; ++f) sum += dp[f * p.V];      // frames past the sequence end are zero-filled
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
                                                                   const float *__restrict__ dz,
                                                                   const float *__restrict__ Wt,
                                                                   const uint8_t *__restrict__ nbr,
+                                                                  const float *__restrict__ coef,
                                                                   float *__restrict__ dcoef_partial) {
   extern __shared__ float lds[];
   float4 *xs4 = reinterpret_cast<float4 *>(lds);                     // [16 row groups][DC_ROW4] float4
@@ -599,13 +601,16 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
   const int r = lane & 15;
 
   for (int e = tid; e < ltot * p.V; e += DC_THREADS) {
-    tbl[e] = make_int2((int)nbr[e], 0);
+    // .y = 1 marks a real list slot: non-zero coefficient when the coefficient table is given, otherwise slot 0 and
+    // every later slot with a non-zero joint (lists are sorted and padded with joint 0)
+    const int nb = (int)nbr[e];
+    tbl[e] = make_int2(nb, coef ? (coef[e] != 0.f ? 1 : 0) : (nb != 0 ? 1 : 2));
     dcs[e] = 0.f;
   }
   __syncthreads();
   // A tile's columns keep their joint across the persistent loop (column = frame * V + joint, tiles start at
-  // whole frames), so the longest real list among a wave's 16 columns is fixed per (n-tile, plane): lists
-  // are sorted and padded with joint 0, i.e. slot j >= 1 is real iff its entry is non-zero.
+  // whole frames), so the longest real list among a wave's 16 columns is fixed per (n-tile, plane); with the
+  // coefficient table a plane that reaches none of the 16 columns gets length 0 and its MFMAs are skipped.
   int tlen[GC_NT16];                       // plane k's value lives in lane k of the wave
 #pragma unroll
   for (int i = 0; i < GC_NT16; ++i) {
@@ -614,9 +619,11 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
     const int w = in ? col % p.V : 0;
     int mine = 0;
     for (int k = 0; k < p.K; ++k) {
-      int len = in ? 1 : 0;
-      for (int j = 1; j < p.Lk[k]; ++j)
-        if (in && tbl[(p.Lofs[k] + j) * p.V + w].x != 0) len = j + 1;
+      int len = 0;
+      for (int j = 0; j < p.Lk[k]; ++j) {
+        const int mark = tbl[(p.Lofs[k] + j) * p.V + w].y;       // 1 real, 0 padding, 2 "joint 0 without coefficients"
+        if (in && (mark == 1 || (mark == 2 && j == 0))) len = j + 1;
+      }
       // wave maximum by ballots over the candidate lengths
       int m = 0;
       for (int c = 1; c <= p.Lk[k]; ++c)
@@ -684,6 +691,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
 #pragma unroll
       for (int i = 0; i < GC_NT16; ++i) {
         const int L = __builtin_amdgcn_readlane(tlen[i], k);   // longest real list in this n-tile
+        if (L == 0) continue;                                  // plane k reaches none of these columns
         floatx4_t h[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) h[m] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -727,13 +735,15 @@ static int gcn_fill_params(GcnParams &p, int T, int V, int K, const int *Lk_host
   return ofs;
 }
 
-// dW partials: x, dz (N,64,T,V) -> dw_partial [n_blocks][K][64][64]; the caller sums
-// over the leading axis.  colsum_partial (optional) [n_blocks][64][V] = per-workgroup sums of dz
-// over samples and frames (gradient of the bias table), also summed by the caller.  Returns the number of workgroups used through *n_blocks
+// dW partials: x, dz (N,64,T,V) -> dw_partial [n_blocks][K][64][64] = sum over columns of
+// dz[row][col] * (x . lists)[column-of-partial][col]; the caller sums over the leading axis.
+// colsum_partial (optional) [n_blocks][64][V] = per-workgroup sums over samples and frames of the
+// `dz` argument (or of the `x` argument when colsum_of_x != 0), also summed by the caller.  Returns the number of workgroups used through *n_blocks
 // when dw_partial is NULL (size query), else launches.  K must be 11.
 extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host, const float *x,
                                          const float *dz, const uint8_t *nbr, const float *coef,
-                                         int n_blocks, float *dw_partial, float *colsum_partial, void *stream) {
+                                         int n_blocks, float *dw_partial, float *colsum_partial, int colsum_of_x,
+                                         void *stream) {
   GcnParams p;
   const int ltot = gcn_fill_params(p, T, V, K, Lk_host, DW_F);
   if (ltot < 0) return ltot;
@@ -767,7 +777,7 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
     attr_set = true;
   }
   hipLaunchKernelGGL(gcn_dw_kernel, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
-                     row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial);
+                     row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial, colsum_of_x);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -775,7 +785,7 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
 // dcoef partials: x, dz (N,64,T,V), Wt [K][64(ci)][64(c)] (transposed planes) ->
 // dcoef_partial [n_blocks][sum L_k][V]; the caller sums over the leading axis.
 extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host, const float *x,
-                                       const float *dz, const float *Wt, const uint8_t *nbr,
+                                       const float *dz, const float *Wt, const uint8_t *nbr, const float *coef,
                                        int n_blocks, float *dcoef_partial, void *stream) {
   GcnParams p;
   const int ltot = gcn_fill_params(p, T, V, K, Lk_host, GC_NP / (V > 0 ? V : 1));
@@ -792,7 +802,7 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
     attr_set = true;
   }
   hipLaunchKernelGGL(gcn_dcoef_kernel, dim3(n_blocks), dim3(DC_THREADS), lds, p2r_stream(stream), p, N, ltot, x,
-                     dz, Wt, nbr, dcoef_partial);
+                     dz, Wt, nbr, coef, dcoef_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

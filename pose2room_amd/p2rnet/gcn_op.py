@@ -80,7 +80,7 @@ class _GraphConv(Function):
         N, C, T, V = x.shape
         K = tables.K
         Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
-        dx = dW = dcoef = dbias = None
+        dx = dW = dcoef_r = dbias = None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
             dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
@@ -88,29 +88,35 @@ class _GraphConv(Function):
         st = _lib.current_stream(dev)
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[1]:
+                # dW_k[c][ci] = sum_cols dz[c] * (x . A_k)[ci] = sum_cols (dz . A_k^T)[c] * x[ci]: the second form
+                # aggregates on the gradient side through the ROW lists, whose (plane, 4-joint group) units are
+                # empty ~30 % of the time (skipped); the kernel then returns dW_k transposed
                 part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
                 # the bias-table gradient (column sums of dz) rides on the same pass over dz
                 bpart = torch.empty((_N_BLOCKS, C, V), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
                 _lib.check(lib.p2r_stgcn_gcn_weight_grad(
-                    N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(t['nbr_c']),
-                    _lib.ptr(coef_c.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
+                    N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(t['nbr_r']),
+                    _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), 1, st),
                     "stgcn_gcn_weight_grad")
-                dW = part.sum(0).view(K * C, C)
+                dW = part.sum(0).transpose(1, 2).reshape(K * C, C)
                 if bpart is not None:
                     dbias = bpart.sum(0)                                   # (C, V)
-            if ctx.needs_input_grad[2]:
-                ltot = coef_c.shape[0]
+            if ctx.needs_input_grad[3]:
+                # adjacency gradient in ROW-list form: Y_k = W_k . x on MFMA, reduced against dz gathered through
+                # the row lists (same kernel as the column form with the roles of x and dz swapped); the row lists
+                # leave ~20 % of the (plane, 16-column) units empty, which the kernel skips
+                ltot = coef_r.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_stgcn_gcn_coef_grad(
-                    N, T, V, K, tables.LkA_c, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wt), _lib.ptr(t['nbr_c']),
-                    _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
-                dcoef = part.sum(0)
+                    N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(W), _lib.ptr(t['nbr_r']),
+                    _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
+                dcoef_r = part.sum(0)
         if ctx.needs_input_grad[4] and dbias is None:
             part = torch.empty((N * C, V), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
-        return dx, dW, dcoef, None, dbias, None, None
+        return dx, dW, None, dcoef_r, dbias, None, None
 
 
 def supported(x, weight, A):
@@ -126,8 +132,8 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False):
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)
-    coef_c = gcn_tables.coefficients(Aeff, t['gidx_c'])
-    coef_r = gcn_tables.coefficients(Aeff.detach(), t['gidx_r'])      # only used for dX
+    coef_c = gcn_tables.coefficients(Aeff.detach(), t['gidx_c'])      # forward lists (values only)
+    coef_r = gcn_tables.coefficients(Aeff, t['gidx_r'])               # backward lists; carries the gradient to Aeff
     if bias is not None:
         bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
     else:

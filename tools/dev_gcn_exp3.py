@@ -18,7 +18,7 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     def call():
-        assert lib.p2r_stgcn_gcn_weight_grad(N, T, V, K, LkA, p(x), p(dz), p(nb), p(coef), 256, p(part), None, st) == 0
+        assert lib.p2r_stgcn_gcn_weight_grad(N, T, V, K, LkA, p(x), p(dz), p(nb), p(coef), 256, p(part), None, 0, st) == 0
     for _ in range(2): call()
     ts = []
     for rep in range(3):

@@ -23,7 +23,7 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     part = torch.zeros(256, ltot, V, device=dev)
     def call():
-        assert lib.p2r_stgcn_gcn_coef_grad(N, T, V, K, LkA, p(x), p(dz), p(Wt), p(nb), 256, p(part), st) == 0
+        assert lib.p2r_stgcn_gcn_coef_grad(N, T, V, K, LkA, p(x), p(dz), p(Wt), p(nb), None, 256, p(part), st) == 0
     for _ in range(2): call()
     ts = []
     for rep in range(3):
