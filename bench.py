@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                   the ops ("port"), on a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -225,6 +226,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Python's cyclic GC: the first full (generation-2) collection of a process walks every object torch and the
+    # model have created -- a ~100 ms host pause that lands around the 11th step (measured, tools/step_times2.py).
+    # Collect now and freeze the survivors so later collections only look at the objects of the steps themselves.
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -20,3 +20,8 @@ for _ in range(6):
     issue.append((t1 - t0, t2 - t1, t3 - t2)); wall.append(t4 - t0)
 f = sum(i[0] for i in issue) / len(issue) * 1e3; b = sum(i[1] for i in issue) / len(issue) * 1e3; o = sum(i[2] for i in issue) / len(issue) * 1e3
 print(f'host enqueue: forward+loss {f:.1f} ms, backward {b:.1f} ms, optimizer {o:.1f} ms; step wall {sum(wall) / len(wall) * 1e3:.1f} ms')
+# the bench way: K train_step calls (each ends with the loss-dict transfer), one synchronize at the end
+for K in (8, 8):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(K): trainer.train_step(dict(batch))
+    torch.cuda.synchronize(); print(f'train_step loop: {(time.perf_counter() - t0) / K * 1e3:.1f} ms/step')
