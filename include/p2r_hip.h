@@ -187,8 +187,10 @@ int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *Lk_host,
  * planes with rows = the reduce index of dz's channels.  Two equivalent ways to call it:
  * (x, dz, transposed planes, column lists) or (dz, x, forward planes, row lists) -- the
  * second one lets whole (plane, 16-column) units be skipped, the row lists being emptier.
- * coef (the list's coefficient table, or NULL) is only used to tell real slots from padding;
- * without it every slot 0 counts as real and nothing is skipped. */
+ * coef ([sum_k Lk][V] floats or NULL) only tells real slots (non-zero) from padding (zero): pass a
+ * 0/1 table of the adjacency pattern rather than the current coefficients, since a real entry whose
+ * coefficient is momentarily zero still has a gradient; with NULL every slot 0 and every later slot
+ * holding a non-zero joint counts as real and no unit is skipped. */
 int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
                             const float *x, const float *dz, const float *Wt,
                             const uint8_t *nbr, const float *coef, int n_blocks,

@@ -36,7 +36,10 @@ class GraphTables:
         key = str(device)
         if key not in self._dev:
             self._dev[key] = dict(nbr_c=self.nbr_c.to(device), gidx_c=self.gidx_c.to(device),
-                                  nbr_r=self.nbr_r.to(device), gidx_r=self.gidx_r.to(device))
+                                  nbr_r=self.nbr_r.to(device), gidx_r=self.gidx_r.to(device),
+                                  # 1 for a real list slot, 0 for padding (the adjacency gradient must also reach
+                                  # real entries whose current coefficient happens to be zero)
+                                  real_r=(self.gidx_r >= 0).to(torch.float32).to(device).contiguous())
         return self._dev[key]
 
 
@@ -109,7 +112,7 @@ class _GraphConv(Function):
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_stgcn_gcn_coef_grad(
                     N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(W), _lib.ptr(t['nbr_r']),
-                    _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
+                    _lib.ptr(t['real_r']), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
                 dcoef_r = part.sum(0)
         if ctx.needs_input_grad[4] and dbias is None:
             part = torch.empty((N * C, V), dtype=torch.float32, device=dev)

@@ -90,3 +90,32 @@ def test_graph_conv_emitted_statistics(dev, N, T):
     zd = z.double()
     torch.testing.assert_close(mean, zd.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(var, zd.var(dim=(0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
+def test_adjacency_gradient_reaches_zero_valued_entries(dev):
+    """An entry of A * importance that is exactly zero right now still gets its gradient (the kernels skip
+    padding by the adjacency PATTERN, not by the current coefficient values)."""
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    torch.manual_seed(9)
+    N, T = 2, 21
+    x = torch.randn(N, 64, T, V, device=dev)
+    w = torch.randn(K * 64, 64, device=dev) / 8
+    b = torch.randn(K * 64, device=dev) * 0.1
+    At = torch.tensor(A, dtype=torch.float32, device=dev)
+    imp = torch.ones(K, V, V, device=dev)
+    nz = (At != 0).nonzero()
+    for (k, v, ww) in nz[::7].tolist():            # zero every 7th real entry
+        imp[k, v, ww] = 0.0
+    go = torch.randn(N, 64, T, V, device=dev)
+    ia = imp.clone().requires_grad_(True)
+    gcn_op.graph_conv(x, w, b, At * ia, tables).backward(go)
+    ib = imp.double().clone().requires_grad_(True)
+    _reference(x.double(), w.double(), b.double(), At.double() * ib).backward(go.double())
+    scale = ib.grad.abs().max().item()
+    assert (ia.grad.double() - ib.grad).abs().max().item() <= 2e-4 * scale
+    zeroed = imp == 0
+    assert (ib.grad[zeroed & (At != 0)].abs() > 1e-3 * scale).any()      # those gradients are not trivially zero
