@@ -203,13 +203,16 @@ int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
 int p2r_bn_stats(int rows, int L, const float *x, float *partial, void *stream);
 
 /* y = relu?(x * scale[c] + shift[c] + res?)  over x (N,C,L); res may be NULL.
- * Replaces BatchNorm2d (normalise with given statistics) -> [+ residual] -> ReLU. */
+ * Replaces BatchNorm2d (normalise with given statistics) -> [+ residual] -> ReLU.
+ * relu_mask, when not NULL (and relu != 0), receives one byte per element (y > 0): the
+ * backward kernels then read 1 byte instead of the 4 bytes of y (relu mode 3 below). */
 int p2r_bn_apply(int N, int C, int L, const float *x, const float *scale,
                  const float *shift, const float *res, int relu, float *y,
-                 void *stream);
+                 unsigned char *relu_mask, void *stream);
 
 /* backward reductions: g = dy * mask, mask by `relu`: 0 none, 1 (y > 0), 2 recomputed
- * (x * mscale[c] + mshift[c] > 0); partial [N*C][2] = (sum g, sum g * xhat),
+ * (x * mscale[c] + mshift[c] > 0), 3 = the byte map of p2r_bn_apply passed through the `y`
+ * pointer; partial [N*C][2] = (sum g, sum g * xhat),
  * xhat = (x - mean[c]) * invstd[c]. */
 int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y,
                       const float *x, const float *mean, const float *invstd,

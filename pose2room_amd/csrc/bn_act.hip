@@ -64,7 +64,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift,
                                                               const float *__restrict__ res,
-                                                              float *__restrict__ y) {
+                                                              float *__restrict__ y,
+                                                              unsigned char *__restrict__ mask) {
   const int rowi = blockIdx.x / chunks;
   const int chunk = blockIdx.x % chunks;
   const int c = rowi % C;
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       }
       if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       *reinterpret_cast<float4 *>(y + base + i) = v;
+      if (RELU && mask)     // one byte per element (y > 0): the backward reads 1 B instead of the 4 B of y
+        *reinterpret_cast<uchar4 *>(mask + base + i) = make_uchar4(v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
     }
     // ragged tail of this chunk: elements [hi - (hi-lo)%4, hi)
     const int tail = lo + ((hi - lo) & ~3);
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       if (RES) v += res[base + j];
       if (RELU) v = fmaxf(v, 0.f);
       y[base + j] = v;
+      if (RELU && mask) mask[base + j] = v > 0.f;
     }
   } else {
     for (int j = lo + threadIdx.x; j < hi; j += BN_THREADS) {
@@ -100,13 +104,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       if (RES) v += res[base + j];
       if (RELU) v = fmaxf(v, 0.f);
       y[base + j] = v;
+      if (RELU && mask) mask[base + j] = v > 0.f;
     }
   }
 }
 
 // partial[row] = (sum g, sum g * xhat),  g = dy * (RELU ? y > 0 : 1),  xhat = (x - mean) * invstd
 // MASK: 0 = no ReLU, 1 = ReLU mask from the saved output y (> 0), 2 = ReLU mask recomputed
-// from the input (x * mscale[c] + mshift[c] > 0; the normalised activation was never stored).
+// from the input (x * mscale[c] + mshift[c] > 0; the normalised activation was never stored),
+// 3 = ReLU mask from the byte map written by bn_apply (passed through the `y` pointer).
 template <int MASK>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L, const float *__restrict__ dy,
                                                                    const float *__restrict__ y,
@@ -122,11 +128,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L,
   const float msc = MASK == 2 ? mscale[c] : 0.f, msh = MASK == 2 ? mshift[c] : 0.f;
   const size_t base = (size_t)blockIdx.x * L;
   float s = 0.f, q = 0.f;
-  const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (RELU ? (uintptr_t)(y + base) : 0)) % 16 == 0);
+  const unsigned char *m8 = reinterpret_cast<const unsigned char *>(y);
+  const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (RELU ? (uintptr_t)(y + base) : 0)) % 16 == 0) &&
+                   (MASK != 3 || (base % 4 == 0 && (uintptr_t)m8 % 4 == 0));
   const int L4 = vec ? (L >> 2) : 0;
   for (int i = threadIdx.x; i < L4; i += BN_THREADS) {
     float4 g = reinterpret_cast<const float4 *>(dy + base)[i];
     const float4 xv = reinterpret_cast<const float4 *>(x + base)[i];
+    if (MASK == 3) {
+      const uchar4 mk = reinterpret_cast<const uchar4 *>(m8 + base)[i];
+      g.x = mk.x ? g.x : 0.f; g.y = mk.y ? g.y : 0.f; g.z = mk.z ? g.z : 0.f; g.w = mk.w ? g.w : 0.f;
+    }
     if (RELU) {
       const float4 yv = reinterpret_cast<const float4 *>(y + base)[i];
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
@@ -143,6 +155,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L,
     float g = dy[base + i];
     if (RELU) g = y[base + i] > 0.f ? g : 0.f;
     if (MASK == 2) g = fmaf(x[base + i], msc, msh) > 0.f ? g : 0.f;
+    if (MASK == 3) g = m8[base + i] ? g : 0.f;
     s += g; q += g * ((x[base + i] - mu) * is);
   }
   block_sum2(s, q);
@@ -173,15 +186,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
   const size_t base = (size_t)rowi * L;
   const int per = (((L + chunks - 1) / chunks) + 3) & ~3;   // multiple of 4: chunk starts stay 16-byte aligned
   const int lo = chunk * per, hi = min(L, lo + per);
+  const unsigned char *m8 = reinterpret_cast<const unsigned char *>(y);
   auto one = [&](float g, float yv, float xv, float &dxo, float &dro) {
-    if (RELU) g = yv > 0.f ? g : 0.f;
+    if (RELU || MASK == 3) g = yv > 0.f ? g : 0.f;       // MASK 3: yv carries the mask byte
     if (MASK == 2) g = fmaf(xv, msc, msh) > 0.f ? g : 0.f;
     const float xh = (xv - mu) * is;
     dxo = kk * (g - a1 - xh * a2);
     dro = g;
   };
   const bool vec = (((uintptr_t)(dy + base) | (uintptr_t)(x + base) | (uintptr_t)(dx + base) |
-                     (RELU ? (uintptr_t)(y + base) : 0) | (RES ? (uintptr_t)(dres + base) : 0)) % 16 == 0);
+                     (RELU ? (uintptr_t)(y + base) : 0) | (RES ? (uintptr_t)(dres + base) : 0)) % 16 == 0) &&
+                   (MASK != 3 || (base % 4 == 0 && (uintptr_t)m8 % 4 == 0));
   int tail = lo;
   if (vec) {
     tail = lo + ((hi - lo) & ~3);
@@ -190,6 +205,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
       const float4 x4 = *reinterpret_cast<const float4 *>(x + base + j);
       float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (RELU) y4 = *reinterpret_cast<const float4 *>(y + base + j);
+      if (MASK == 3) {
+        const uchar4 mk = *reinterpret_cast<const uchar4 *>(m8 + base + j);
+        y4 = make_float4((float)mk.x, (float)mk.y, (float)mk.z, (float)mk.w);
+      }
       float4 o, rr;
       one(g4.x, y4.x, x4.x, o.x, rr.x); one(g4.y, y4.y, x4.y, o.y, rr.y);
       one(g4.z, y4.z, x4.z, o.z, rr.z); one(g4.w, y4.w, x4.w, o.w, rr.w);
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
   }
   for (int j = tail + threadIdx.x; j < hi; j += BN_THREADS) {
     float o, rr;
-    one(dy[base + j], RELU ? y[base + j] : 0.f, x[base + j], o, rr);
+    one(dy[base + j], RELU ? y[base + j] : (MASK == 3 ? (float)m8[base + j] : 0.f), x[base + j], o, rr);
     dx[base + j] = o;
     if (RES) dres[base + j] = rr;
   }
@@ -223,16 +242,16 @@ static int bn_chunks(int rows, int L) {
 }
 
 extern "C" int p2r_bn_apply(int N, int C, int L, const float *x, const float *scale, const float *shift,
-                            const float *res, int relu, float *y, void *stream) {
+                            const float *res, int relu, float *y, unsigned char *relu_mask, void *stream) {
   if (N < 0 || C <= 0 || L <= 0) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   const int rows = N * C, chunks = bn_chunks(rows, L);
   dim3 grid(rows * chunks), blk(BN_THREADS);
   hipStream_t st = p2r_stream(stream);
-  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
-  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
-  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
-  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y);
+  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, relu_mask);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, relu_mask);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, relu_mask);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, relu_mask);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -240,11 +259,12 @@ extern "C" int p2r_bn_apply(int N, int C, int L, const float *x, const float *sc
 extern "C" int p2r_bn_bwd_reduce(int N, int C, int L, const float *dy, const float *y, const float *x,
                                  const float *mean, const float *invstd, int relu, const float *mscale,
                                  const float *mshift, float *partial, void *stream) {
-  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 2) return P2R_EINVAL;
+  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 3) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   hipStream_t st = p2r_stream(stream);
   float2 *pp = reinterpret_cast<float2 *>(partial);
-  if (relu == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
+  if (relu == 3) hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
+  else if (relu == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
   else if (relu == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(N * C), dim3(BN_THREADS), 0, st, C, L, dy, y, x, mean, invstd, mscale, mshift, pp);
   P2R_LAUNCH_CHECK();
@@ -255,13 +275,15 @@ extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const floa
                                 const float *mean, const float *invstd, const float *kscale,
                                 const float *m1, const float *m2, int relu, const float *mscale,
                                 const float *mshift, float *dx, float *dres, void *stream) {
-  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 2) return P2R_EINVAL;
+  if (N < 0 || C <= 0 || L <= 0 || relu < 0 || relu > 3) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   const int rows = N * C, chunks = bn_chunks(rows, L);
   dim3 grid(rows * chunks), blk(BN_THREADS);
   hipStream_t st = p2r_stream(stream);
 #define P2R_BWA(M, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, R>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd, kscale, m1, m2, mscale, mshift, dx, dres)
-  if (relu == 1 && dres) P2R_BWA(1, true);
+  if (relu == 3 && dres) P2R_BWA(3, true);
+  else if (relu == 3) P2R_BWA(3, false);
+  else if (relu == 1 && dres) P2R_BWA(1, true);
   else if (relu == 1) P2R_BWA(1, false);
   else if (relu == 2 && dres) P2R_BWA(2, true);
   else if (relu == 2) P2R_BWA(2, false);

@@ -76,13 +76,15 @@ def moments(part, M):
     return mean, var, float(M)
 
 
-def _apply(x, scale, shift, res, relu):
+def _apply(x, scale, shift, res, relu, want_mask=False):
     N, C, L = _rows(x)
     y = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().p2r_bn_apply(N, C, L, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
-                                           int(relu), _lib.ptr(y), _lib.current_stream(x.device)), "bn_apply")
-    return y
+                                           int(relu), _lib.ptr(y), _lib.ptr(mask), _lib.current_stream(x.device)),
+                   "bn_apply")
+    return (y, mask) if want_mask else y
 
 
 class _FusedBNAct(Function):
@@ -92,32 +94,34 @@ class _FusedBNAct(Function):
     def forward(ctx, x, weight, bias, res, fin, relu):
         x = x.contiguous()
         res_c = res.contiguous() if res is not None else None
-        y = _apply(x, fin[2], fin[3], res_c, relu)
-        ctx.save_for_backward(x, y, fin)
+        # the ReLU mask is kept as one byte per element, so the backward does not re-read y (4 bytes) twice
+        y, mask = _apply(x, fin[2], fin[3], res_c, relu, want_mask=True)
+        ctx.save_for_backward(x, mask, fin)
         ctx.relu = relu
         ctx.has_res = res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, fin = ctx.saved_tensors
+        x, mask, fin = ctx.saved_tensors
         mean, invstd, kscale = fin[0], fin[1], fin[2]
+        mode = 3 if ctx.relu else 0
         dy = dy.contiguous()
         N, C, L = _rows(x)
         dev = x.device
         lib = _lib.lib()
         part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
-                                             _lib.ptr(invstd), int(ctx.relu), None, None, _lib.ptr(part),
+            _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
+                                             _lib.ptr(invstd), mode, None, None, _lib.ptr(part),
                                              _lib.current_stream(dev)), "bn_bwd_reduce")
         tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         with torch.cuda.device(dev):
-            _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
+            _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
-                                            int(ctx.relu), None, None, _lib.ptr(dx), _lib.ptr(dres),
+                                            mode, None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
         return dx, tot[1], tot[0], dres, None, None
 
