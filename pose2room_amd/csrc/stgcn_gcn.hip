@@ -87,12 +87,15 @@ __device__ __forceinline__ void agg_mfma16(const float4 *__restrict__ xg4, const
         b[2] = fmaf(c, xc[j].z, b[2]); b[3] = fmaf(c, xc[j].w, b[3]);
       }
     if (hf == H - 1) {
+      __builtin_amdgcn_s_setprio(1);       // the wave that has its B operands ready goes first: the SIMD's other wave
+                                           // is then in its gather phase, which fits under these MFMAs
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][4 * qd + t], b[t], acc[m], 0, 0, 0);
       }
+      __builtin_amdgcn_s_setprio(0);
       b[0] = b[1] = b[2] = b[3] = 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 #pragma unroll
           for (int m = 0; m < 4; ++m)
             acc[kk][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f], b[f], acc[kk][m], 0, 0, 0);
+
       }
     }
   }
