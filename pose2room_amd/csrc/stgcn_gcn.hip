@@ -98,7 +98,6 @@ __device__ __forceinline__ void agg_mfma16(const float4 *__restrict__ xg4, const
       __builtin_amdgcn_s_setprio(0);
       b[0] = b[1] = b[2] = b[3] = 0.f;
     }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < LC; ++j) xc[j] = xn[j];
   }
