@@ -645,6 +645,22 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
     const int ncols = min(p.F, p.T - t0) * p.V;
     const float *xgm = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    // the B operands of this tile are requested first: their HBM latency then overlaps the wait for the other
+    // waves (barrier) and the staging of the gather tile
+    int fbase[GC_NT16], wj[GC_NT16];
+    bool valid[GC_NT16];
+    float bz[GC_NT16][16];               // dZ[c = 16g + s][col]: B operands, reused by every plane
+#pragma unroll
+    for (int i = 0; i < GC_NT16; ++i) {
+      const int col = (wave * GC_NT16 + i) * 16 + r;
+      valid[i] = col < ncols;
+      const int f = valid[i] ? col / p.V : 0;
+      wj[i] = valid[i] ? col - f * p.V : 0;
+      fbase[i] = f * p.V;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + col] : 0.f;
+    }
     __syncthreads();
 #pragma unroll 1
     for (int rg = wave; rg < GC_C / 4; rg += DC_THREADS / 64) {       // row group = 4 consecutive rows
@@ -663,20 +679,6 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         xs4[rg * DC_ROW4 + 64 * i + lane] = make_float4(v[0][i], v[1][i], v[2][i], v[3][i]);
     }
 
-    int fbase[GC_NT16], wj[GC_NT16];
-    bool valid[GC_NT16];
-    float bz[GC_NT16][16];               // dZ[c = 16g + s][col]: B operands, reused by every plane
-#pragma unroll
-    for (int i = 0; i < GC_NT16; ++i) {
-      const int col = (wave * GC_NT16 + i) * 16 + r;
-      valid[i] = col < ncols;
-      const int f = valid[i] ? col / p.V : 0;
-      wj[i] = valid[i] ? col - f * p.V : 0;
-      fbase[i] = f * p.V;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + col] : 0.f;
-    }
     __syncthreads();
 
     for (int k = 0; k < p.K; ++k) {
