@@ -414,11 +414,38 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
     const int ncols = min(DW_F, p.T - t0) * p.V;
     const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
     const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    __syncthreads();  // previous tile fully consumed (and the table written, first time)
-    // stage both tiles: all loads of two rows are issued before the first LDS write so the
-    // HBM latency is paid once per row pair, not once per 64-column chunk
+    // stage both tiles: all loads of two rows are issued before the first LDS write so the HBM latency is paid
+    // once per row pair, not once per 64-column chunk; the first row pair is requested BEFORE the barrier that
+    // waits for the other waves to finish the previous tile, so its latency overlaps that wait
+    {
+      const int c = wave;
+      float vx[2][4], vd[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float *sx = xg + (size_t)(c + 8 * h) * row_stride;
+        const float *sd = dg + (size_t)(c + 8 * h) * row_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = lane + 64 * i;
+          const bool in = q < ncols;
+          vx[h][i] = in ? sx[q] : 0.f;
+          vd[h][i] = in ? sd[q] : 0.f;
+        }
+      }
+      __syncthreads();  // previous tile fully consumed (and the table written, first time)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = lane + 64 * i;
+          if (q < row_len) {
+            xs[(c + 8 * h) * row_len + q] = vx[h][i];
+            dzs[(c + 8 * h) * row_len + q] = vd[h][i];
+          }
+        }
+    }
 #pragma unroll 1
-    for (int c = wave; c < GC_C; c += 2 * (DW_THREADS / 64)) {
+    for (int c = wave + 2 * (DW_THREADS / 64); c < GC_C; c += 2 * (DW_THREADS / 64)) {
       float vx[2][4], vd[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
