@@ -158,14 +158,19 @@ def assembly_pred_map_cls(eval_dict, parsed_predictions, config_dict, mesh_outpu
     pred_sem_cls = parsed_predictions['pred_sem_cls']
     bsize, n_prop = pred_sem_cls.shape
     out = []
+    conf = config_dict['conf_thresh']
     for i in range(bsize):
-        keep = [j for j in range(n_prop) if pred_mask[i, j] == 1 and obj_prob[i, j] > config_dict['conf_thresh']]
+        # same lists as the reference's nested comprehensions (class-major, then proposal index); the scores are
+        # formed with one array product per sample instead of one NumPy scalar product per tuple
+        keep = np.nonzero((pred_mask[i] == 1) & (obj_prob[i] > conf))[0]
+        boxes = [pred_corners_3d[i, j] for j in keep]
         if config_dict['per_class_proposal']:
+            scores = sem_cls_probs[i][keep] * obj_prob[i][keep, None]          # (n_keep, num_class)
             cur = []
             for ii in range(config_dict['dataset_config'].num_class):
-                cur += [(ii, pred_corners_3d[i, j], sem_cls_probs[i, j, ii] * obj_prob[i, j]) for j in keep]
+                cur += list(zip([ii] * len(boxes), boxes, scores[:, ii]))
         else:
-            cur = [(pred_sem_cls[i, j].item(), pred_corners_3d[i, j], obj_prob[i, j]) for j in keep]
+            cur = list(zip(pred_sem_cls[i][keep].tolist(), boxes, obj_prob[i][keep]))
         out.append(cur)
     eval_dict['batch_pred_map_cls'] = out
     return eval_dict
