@@ -35,6 +35,17 @@ def _worker(rank, world, port, out):
     # reduce_dict averages across ranks
     r = reduce_dict({'a': torch.tensor(float(rank)), 'b': torch.tensor(2.0 * rank)})
     assert abs(r['a'].item() - 0.5) < 1e-6 and abs(r['b'].item() - 1.0) < 1e-6
+    # loss meters of the test loop: counts and sums are summed over ranks (net_utils/utils.py:319-327)
+    from pose2room_amd.p2rnet.testing import LossRecorder
+    rec = LossRecorder(batch_size=4)
+    rec.update_loss({'total': 1.0 + rank})          # rank 0: 4 samples at 1.0, rank 1: 4 samples at 2.0
+    rec.synchronize_between_processes(torch.device('cpu'))
+    m = rec.loss_recorder['total']
+    assert m.count == 8 and abs(m.sum - 12.0) < 1e-9 and abs(m.avg - 1.5) < 1e-9
+    # the sample list is sharded by rank (dataloader.py:180: DistributedSampler)
+    from torch.utils.data.distributed import DistributedSampler
+    idx = list(DistributedSampler(list(range(10)), shuffle=False))
+    assert idx == list(range(rank, 10, 2))
     dist.destroy_process_group()
 
 
