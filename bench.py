@@ -211,10 +211,18 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    # P2R_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0 with gloo collectives, to exercise the multi-rank
+    # code path (DDP hooks on the HIP autograd functions, barriers, max-over-ranks timing) on a 1-GPU box
+    share = os.environ.get('P2R_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+        if share:
+            dist.init_process_group(backend='gloo', init_method='env://')
+        else:
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from pose2room_amd.p2rnet.synthetic import make_batch

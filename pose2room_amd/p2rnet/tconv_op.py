@@ -94,7 +94,8 @@ class _BNReLUTConv(Function):
             _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
                                                        _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
                        "stgcn_tconv_weight_grad")
-            dW = part.sum(0).permute(1, 2, 0).reshape(ctx.wshape).contiguous()
+            # flattened first: a size-1 tap axis would otherwise keep the permuted stride, which DDP's bucket views reject
+            dW = part.sum(0).permute(1, 2, 0).reshape(-1).view(ctx.wshape)
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
                 dbias = bpart.double().sum(0).float()
         return dz, dgamma, dbeta, None, dW, dbias, None, None
