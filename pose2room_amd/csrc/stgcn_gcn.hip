@@ -308,9 +308,9 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
 // reduction steps are ordered (joint w major, frame minor) so the 4 columns of one
 // v_mfma_f32_16x16x4_f32 step are the 4 frames of ONE joint: the neighbour list of
 // (k, w) is then wave-uniform (scalar loads), every (ci, column) aggregate is built
-// exactly once, and it feeds the 4 output-row tiles.  Each wave keeps its
-// 44 accumulator tiles (11 planes x 64 rows x 16 ci columns) in AGPRs across all its
-// tiles and writes one partial per workgroup; partials are summed deterministically
+// exactly once, and it feeds the 4 output-row tiles.  A wave keeps the accumulator
+// tiles of its planes (12 / DW_SETS planes x 64 rows x 16 ci columns) in registers across all
+// its tiles and writes one partial per workgroup; partials are summed deterministically
 // by the caller.
 // =============================================================================
 namespace {
@@ -319,12 +319,16 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int DW_F = 4;
 constexpr int DW_MAXV = 64;
-constexpr int DW_PL = 6;          // planes per wave half (two halves cover up to 12 planes)
-constexpr int DW_THREADS = 512;
-constexpr int DW_CS = GC_C * DW_MAXV / DW_THREADS;   // (channel, joint) column sums owned per thread
+#ifndef DW_SETS
+#define DW_SETS 4   // 16 waves = four per SIMD at 128 VGPRs: measured 1.45 ms vs 1.58 (12 waves) and 1.68 (8 waves)
+#endif
+constexpr int DW_PL = 12 / DW_SETS;   // planes per wave set (the sets cover up to 12 planes)
+constexpr int DW_THREADS = 64 * 4 * DW_SETS;
+constexpr int DW_NW = DW_THREADS / 64;
+constexpr int DW_CS = (GC_C * DW_MAXV + DW_THREADS - 1) / DW_THREADS;   // (channel, joint) column sums owned per thread
 
-struct DwSets {                   // host-balanced split of the planes over the two wave halves
-  int plane[2][DW_PL];            // plane id or -1
+struct DwSets {                   // host-balanced split of the planes over the DW_SETS groups of four waves
+  int plane[DW_SETS][DW_PL];      // plane id or -1
 };
 
 // b[f] += sum_j coef * X[ci row][frame f, joint nbr_j]  for one plane (accumulates into b).
@@ -352,7 +356,7 @@ __device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstr
   }
 }
 
-__global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSets sets, int n_seq,
+__global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kernel(GcnParams p, DwSets sets, int n_seq,
                                                                int row_len, int ltot,
                                                                const float *__restrict__ x,
                                                                const float *__restrict__ dz,
@@ -422,12 +426,12 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
       float vx[2][4], vd[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float *sx = xg + (size_t)(c + 8 * h) * row_stride;
-        const float *sd = dg + (size_t)(c + 8 * h) * row_stride;
+        const float *sx = xg + (size_t)(c + DW_NW * h) * row_stride;
+        const float *sd = dg + (size_t)(c + DW_NW * h) * row_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          const bool in = q < ncols;
+          const bool in = q < ncols && (c + DW_NW * h) < GC_C;
           vx[h][i] = in ? sx[q] : 0.f;
           vd[h][i] = in ? sd[q] : 0.f;
         }
@@ -438,9 +442,9 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          if (q < row_len) {
-            xs[(c + 8 * h) * row_len + q] = vx[h][i];
-            dzs[(c + 8 * h) * row_len + q] = vd[h][i];
+          if (q < row_len && (c + DW_NW * h) < GC_C) {
+            xs[(c + DW_NW * h) * row_len + q] = vx[h][i];
+            dzs[(c + DW_NW * h) * row_len + q] = vd[h][i];
           }
         }
     }
@@ -449,12 +453,12 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
       float vx[2][4], vd[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float *sx = xg + (size_t)(c + 8 * h) * row_stride;
-        const float *sd = dg + (size_t)(c + 8 * h) * row_stride;
+        const float *sx = xg + (size_t)(c + DW_NW * h) * row_stride;
+        const float *sd = dg + (size_t)(c + DW_NW * h) * row_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          const bool in = q < ncols;
+          const bool in = q < ncols && (c + DW_NW * h) < GC_C;
           vx[h][i] = in ? sx[q] : 0.f;
           vd[h][i] = in ? sd[q] : 0.f;
         }
@@ -464,9 +468,9 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          if (q < row_len) {
-            xs[(c + 8 * h) * row_len + q] = vx[h][i];
-            dzs[(c + 8 * h) * row_len + q] = vd[h][i];
+          if (q < row_len && (c + DW_NW * h) < GC_C) {
+            xs[(c + DW_NW * h) * row_len + q] = vx[h][i];
+            dzs[(c + DW_NW * h) * row_len + q] = vd[h][i];
           }
         }
     }
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
 #pragma unroll
         for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
         // lists longer than six go in two passes: bounds the live gather registers (no scratch)
+#if DW_SETS == 2
         if (Lr <= 1) dw_plane<1>(trow, p.V, xrow, p.V, live, Lr, b);
         else if (Lr <= 3) dw_plane<3>(trow, p.V, xrow, p.V, live, Lr, b);
         else if (Lr <= 6) dw_plane<6>(trow, p.V, xrow, p.V, live, Lr, b);
@@ -517,6 +522,14 @@ __global__ __launch_bounds__(DW_THREADS, 2) void gcn_dw_kernel(GcnParams p, DwSe
           if (Lr <= 9) dw_plane<3>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
           else dw_plane<6>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
         }
+#else
+        // tighter register budget: passes of at most three list entries
+        for (int j0 = 0; j0 < Lr; j0 += 3) {
+          const int rem = Lr - j0;
+          if (rem <= 1) dw_plane<1>(trow + j0 * p.V, p.V, xrow, p.V, live, rem, b);
+          else dw_plane<3>(trow + j0 * p.V, p.V, xrow, p.V, live, rem < 3 ? rem : 3, b);
+        }
+#endif
 #pragma unroll
         for (int f = 0; f < DW_F; ++f)
 #pragma unroll
@@ -779,20 +792,21 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   GcnParams p;
   const int ltot = gcn_fill_params(p, T, V, K, Lk_host, DW_F);
   if (ltot < 0) return ltot;
-  if (K > 2 * DW_PL || N < 0 || n_blocks < 1) return P2R_EINVAL;
+  if (K > DW_SETS * DW_PL || N < 0 || n_blocks < 1) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  // two plane sets with balanced gather work (longest lists first, greedy)
+  // DW_SETS plane sets with balanced gather work (longest lists first, greedy)
   DwSets sets;
-  int cnt[2] = {0, 0}, load[2] = {0, 0}, order[GC_MAXK];
+  int cnt[DW_SETS] = {0}, load[DW_SETS] = {0}, order[GC_MAXK];
   for (int k = 0; k < K; ++k) order[k] = k;
   for (int i = 0; i < K; ++i)
     for (int j = i + 1; j < K; ++j)
       if (p.Lk[order[j]] > p.Lk[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < DW_SETS; ++h)
     for (int i = 0; i < DW_PL; ++i) sets.plane[h][i] = -1;
   for (int i = 0; i < K; ++i) {
-    int h = (load[0] <= load[1]) ? 0 : 1;
-    if (cnt[h] >= DW_PL) h ^= 1;
+    int h = -1;
+    for (int c = 0; c < DW_SETS; ++c)
+      if (cnt[c] < DW_PL && (h < 0 || load[c] < load[h])) h = c;
     sets.plane[h][cnt[h]++] = order[i];
     load[h] += p.Lk[order[i]] + 4;   // gathers + the 16 MFMAs a plane costs per frame group
   }

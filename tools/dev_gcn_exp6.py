@@ -30,4 +30,4 @@ for so in sorted(glob.glob(os.path.join(root, 'pose2room_amd', 'libp2r_exp_*.so'
     dw = lambda: lib.p2r_stgcn_gcn_weight_grad(N, T, V, K, LkA, p(dz), p(x), p(nb), p(coef), 256, p(pw), p(pb), 1, st)
     dc = lambda: lib.p2r_stgcn_gcn_coef_grad(N, T, V, K, LkA, p(dz), p(x), p(W), p(nb), p(real), 256, p(pc), st)
     assert dw() == 0 and dc() == 0
-    print(os.path.basename(so), f'dW {t(dw):.3f} ms  dcoef {t(dc):.3f} ms')
+    print(os.path.basename(so), f"dW {t(dw):.3f} ms  dcoef {t(dc):.3f} ms", "dW checksum %.6e" % pw.sum(0).double().abs().sum().item())
