@@ -174,12 +174,17 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
 
 // ---- weight gradient ------------------------------------------------------------------
 // dW[p][c][ci] = sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-1,w]   (h as above)
-// persistent grid; wave = (ci tile nt = wave&3, row half mh = wave>>2): 3 planes x 2 row
+// persistent grid; wave = (ci tile nt = wave&3, row group mh = wave>>2): TAPS planes x TW_MT row
 // tiles of accumulators; reduction steps of 4 consecutive columns.
 constexpr int TW_F = 4;
+#ifndef TW_WAVES
+#define TW_WAVES 16   // four waves per SIMD: same time as 8 for the 3-tap form, -15 % for the single-tap form
+#endif
+constexpr int TW_THREADS = 64 * TW_WAVES;
+constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves = 4 ci tiles x TW_WAVES/4 row groups)
 
 template <int TAPS>
-__global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
+__global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
     float *__restrict__ dw_partial, float *__restrict__ dbias_partial) {
@@ -191,27 +196,27 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
-  const int nt = wave & 3, mh = wave >> 2;
+  const int nt = wave & 3, mh = wave >> 2;          // 16 ci columns x (64 / TW_MH) c rows per wave
   const int tiles_per_seq = (T + TW_F - 1) / TW_F;
   const int total_tiles = n_seq * tiles_per_seq;
   const size_t row_stride = (size_t)T * V;
 
   // pad columns past the staged chunks (row strides are rounded up) are read by the last partial
   // 4-column step: keep them zero
-  for (int e = tid; e < TC_C * (row_d + row_h); e += TC_THREADS) lds[e] = 0.f;
+  for (int e = tid; e < TC_C * (row_d + row_h); e += TW_THREADS) lds[e] = 0.f;
 
-  float bsum[TC_C / (TC_THREADS / 64)];    // per-lane share of the row sums of dout (bias gradient), rows wave, wave+8, ..
+  float bsum[TC_C / (TW_THREADS / 64)];    // per-lane share of the row sums of dout (bias gradient), rows wave, wave+8, ..
 #pragma unroll
-  for (int h = 0; h < TC_C / (TC_THREADS / 64); ++h) bsum[h] = 0.f;
-  floatx4c acc[TAPS][2];
+  for (int h = 0; h < TC_C / (TW_THREADS / 64); ++h) bsum[h] = 0.f;
+  floatx4c acc[TAPS][TW_MT];
 #pragma unroll
   for (int p = 0; p < TAPS; ++p)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[p][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < TW_MT; ++m) acc[p][m] = floatx4c{0.f, 0.f, 0.f, 0.f};
 
   // Persistent loop with register prefetch: the global loads of the NEXT tile are issued right after the current
   // tile has been written to LDS, so HBM latency and transfer hide under the MFMA phase (one workgroup per CU).
-  constexpr int NR = TC_C / (TC_THREADS / 64);     // rows per wave: wave, wave + 8, ...
+  constexpr int NR = TC_C / (TW_THREADS / 64);     // rows per wave: wave, wave + 8, ...
   float ph_[NR][NH], pd_[NR][4];
   auto issue_loads = [&](int tile) {
     const int seq = tile / tiles_per_seq;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     const long long col0 = (long long)(t0 - HALO) * V;
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
-      const int c = wave + hh * (TC_THREADS / 64);
+      const int c = wave + hh * (TW_THREADS / 64);
       const float *sx = xg + (size_t)c * row_stride;
       const float *sd = dg + (size_t)c * row_stride;
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     __syncthreads();                                   // previous tile fully consumed
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
-      const int c = wave + hh * (TC_THREADS / 64);
+      const int c = wave + hh * (TW_THREADS / 64);
       const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
       bsum[hh] += (pd_[hh][0] + pd_[hh][1]) + (pd_[hh][2] + pd_[hh][3]);
 #pragma unroll
@@ -267,46 +272,50 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_dw_kernel(
     __syncthreads();
     if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
 
-    const float *drow = ds + (32 * mh + r) * row_d + g;       // + 16*m rows, + 4*s columns
-    const float *hrow = hs + (16 * nt + r) * row_h + g;       // + p*V, + 4*s columns
+    const float *drow = ds + (16 * TW_MT * mh + r) * row_d + g;  // + 16*m rows, + 4*s columns
+    const float *hrow = hs + (16 * nt + r) * row_h + g;          // + p*V, + 4*s columns
     const int steps = (TW_F * V + 3) / 4;
     // operands of step s+1 are read while the MFMAs of step s run (the rows are zero-padded past the last step)
-    float a0 = drow[0], a1 = drow[16 * row_d], b[TAPS];
+    float a[TW_MT], b[TAPS];
+#pragma unroll
+    for (int m = 0; m < TW_MT; ++m) a[m] = drow[16 * m * row_d];
 #pragma unroll
     for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * V];
     for (int s = 0; s < steps; ++s) {
-      const float na0 = drow[4 * s + 4], na1 = drow[16 * row_d + 4 * s + 4];
-      float nb[TAPS];
+      float na[TW_MT], nb[TAPS];
+#pragma unroll
+      for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) nb[p] = hrow[p * V + 4 * s + 4];
 #pragma unroll
-      for (int p = 0; p < TAPS; ++p) {
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[p], acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[p], acc[p][1], 0, 0, 0);
-      }
-      a0 = na0; a1 = na1;
+      for (int p = 0; p < TAPS; ++p)
+#pragma unroll
+        for (int m = 0; m < TW_MT; ++m)
+          acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[p], acc[p][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TW_MT; ++m) a[m] = na[m];
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
     }
   }
   if (dbias_partial) {
 #pragma unroll
-    for (int hh = 0; hh < TC_C / (TC_THREADS / 64); ++hh) {
+    for (int hh = 0; hh < TC_C / (TW_THREADS / 64); ++hh) {
       float v = bsum[hh];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) dbias_partial[(size_t)blockIdx.x * TC_C + wave + hh * (TC_THREADS / 64)] = v;
+      if (lane == 0) dbias_partial[(size_t)blockIdx.x * TC_C + wave + hh * (TW_THREADS / 64)] = v;
     }
   }
-  // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 32*mh + 16*m + row, ci = 16*nt + r
+  // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 16*TW_MT*mh + 16*m + row, ci = 16*nt + r
   float *outp = dw_partial + (size_t)blockIdx.x * TAPS * TC_C * TC_C;
 #pragma unroll
   for (int p = 0; p < TAPS; ++p)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TW_MT; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        outp[((size_t)p * TC_C + 32 * mh + 16 * m + 4 * g + q) * TC_C + 16 * nt + r] = acc[p][m][q];
+        outp[((size_t)p * TC_C + 16 * TW_MT * mh + 16 * m + 4 * g + q) * TC_C + 16 * nt + r] = acc[p][m][q];
 }
 
 }  // namespace
@@ -373,7 +382,7 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TC_THREADS), lds, p2r_stream(stream), N, T, V,
+  hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
                      row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
