@@ -127,21 +127,30 @@ class _FusedBNAct(Function):
 
 
 class _EvalBNAct(Function):
-    """eval mode: fixed statistics, y = relu(x*scale + shift + res); gradient to x / res only."""
+    """eval mode: fixed statistics, y = relu(x*scale + shift + res).  scale / shift are torch expressions of
+    bn.weight / bn.bias and the running statistics, so returning their gradients (sum g*x, sum g per channel)
+    lets autograd carry them on to the affine parameters like nn.BatchNorm2d does in eval mode."""
 
     @staticmethod
     def forward(ctx, x, scale, shift, res, relu):
         x = x.contiguous()
         y = _apply(x, scale.contiguous(), shift.contiguous(), res.contiguous() if res is not None else None, relu)
-        ctx.save_for_backward(y, scale)
+        ctx.save_for_backward(x, y, scale)
         ctx.relu, ctx.has_res = relu, res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        y, scale = ctx.saved_tensors
+        x, y, scale = ctx.saved_tensors
         g = dy * (y > 0) if ctx.relu else dy
-        return g * scale.view(1, -1, *([1] * (dy.dim() - 2))), None, None, (g if ctx.has_res else None), None
+        dims = [d for d in range(dy.dim()) if d != 1]
+        dscale = dshift = None
+        if ctx.needs_input_grad[1]:
+            dscale = (g.double() * x).sum(dims).float()
+        if ctx.needs_input_grad[2]:
+            dshift = g.double().sum(dims).float()
+        dx = g * scale.view(1, -1, *([1] * (dy.dim() - 2))) if ctx.needs_input_grad[0] else None
+        return dx, dscale, dshift, (g if ctx.has_res else None), None
 
 
 def supported(x, bn):

@@ -83,6 +83,15 @@ class _BNReLUTConv(Function):
             else:   # eval: statistics are constants, dz = scale * g
                 m1 = torch.zeros(C, device=dev)
                 m2 = torch.zeros(C, device=dev)
+                if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                    # affine gradients as nn.BatchNorm2d gives them in eval mode: with mean / invstd = the running
+                    # statistics the same reduction yields (sum g, sum g * xhat) = (dbeta, dgamma)
+                    part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+                    _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
+                                                     _lib.ptr(invstd), 2, _lib.ptr(scale), _lib.ptr(shift),
+                                                     _lib.ptr(part), st), "bn_bwd_reduce")
+                    tot = bn_op.bwd_finalize(part, N * L)
+                    dbeta, dgamma = tot[0], tot[1]
             dz = torch.empty_like(z)
             _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
@@ -167,5 +176,5 @@ def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False):
         return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
-    fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale])
+    fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale]).detach()
     return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, False, want_stats)

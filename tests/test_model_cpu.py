@@ -132,6 +132,105 @@ def run_g4(net, cfg, data, z, device, ops_ctx):
         np.testing.assert_allclose(got[solid], z[f'g4_post_{name}_head'][solid], rtol=1e-4, atol=1e-5, err_msg=name)
 
 
+GB = os.path.join(os.path.dirname(__file__), "golden", "g4b_backward.npz")
+
+
+def check_packed(z, key, got, tol, floor=0.0, what=None):
+    """Gradient tensor against its fixture record (strided values + (sum, abs-sum, max-abs)).
+    Error bound: tol * max(max-abs of the reference tensor, floor) on every recorded element."""
+    ref = z[key + '_val']
+    stride = int(z[key + '_stride'])
+    scale = max(float(z[key + '_sum'][2]), floor)
+    g = got.detach().flatten()[::stride].double().cpu().numpy()
+    assert g.shape == ref.shape, (key, g.shape, ref.shape)
+    err = float(np.abs(g - ref).max()) if ref.size else 0.0
+    assert err <= tol * scale, f"{what or key}: max err {err:.3e} > {tol:g} * scale {scale:.3e}"
+    return err / scale if scale > 0 else 0.0
+
+
+def run_g4b(net, data, z, device, ops_ctx, tol):
+    """Backbone + voting backward, train-mode BatchNorm: forward to the votes, then back-propagate the
+    REFERENCE's recorded seam gradients (d total / d vote_xyz, d vote_features) through our backbone and
+    compare ~60 parameter gradients with the reference's.  Feeding the recorded seam gradient keeps the
+    check independent of discrete flips (ball-query membership) in the head."""
+    net.train()
+    net.zero_grad()
+    with ops_ctx():
+        xyz, feats, ep = net._votes(data)
+        gx = torch.from_numpy(z['g4b_dvote_xyz_full']).to(device)
+        gf = torch.from_numpy(z['g4b_dvote_features_full']).to(device)
+        torch.autograd.backward([xyz, feats], [gx, gf])
+    assert np.array_equal(ep['seed_inds'].cpu().numpy(), z['g4b_seed_inds'])
+    params = dict(net.named_parameters())
+    names = [str(n) for n in z['g4b_names']]
+    assert len(names) >= 50 and sum(n.startswith('backbone.st_gcn_networks') for n in names) == 24
+    # floor: gradients that vanish analytically (a conv bias in front of a train-mode BatchNorm) are cancellation
+    # noise of the summands; they are compared on the scale of the largest backbone gradient
+    floor = 1e-3 * max(float(z[f'g4b_grad_{n}_sum'][2]) for n in names)
+    worst = {}
+    for n in names:
+        worst[n] = check_packed(z, f'g4b_grad_{n}', params[n].grad, tol, floor, n)
+    return worst
+
+
+def run_g4e(net, data, z, device, ops_ctx, tol=1e-4):
+    """Every BatchNorm in eval mode (running statistics), autograd on: the whole step end to end against
+    the reference at the north star's 1e-4 -- outputs, the 10 losses (with dtypes), and the gradients of
+    all recorded parameters (fused ST-GCN forward AND backward without batch-statistics amplification)."""
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    net.zero_grad()
+    data = dict(data)
+    data['center_label'] = torch.from_numpy(z['g4e_center_label']).to(device)
+    eps = {}
+    g = torch.Generator().manual_seed(123)
+    B = data['input_joints'].shape[0]
+    for head, dt, D in (('center', torch.float32, 3), ('size', torch.float32, 3), ('heading', torch.float64, 2)):
+        eps[head] = torch.empty(B * 128, 100, 1, D, dtype=dt).normal_(generator=g).to(device)
+    with ops_ctx():
+        ep = net(data, eps=eps)
+        ep['vote_xyz'].retain_grad()
+        ep['vote_features'].retain_grad()
+        loss = net.loss(ep, data)
+        loss['total'].backward()
+    check_endpoints(z, 'g4e', ep)
+    for k, v in loss.items():
+        assert str(v.dtype) == str(z[f'g4e_lossdtype_{k}']), (k, v.dtype)
+        np.testing.assert_allclose(v.item(), float(z[f'g4e_loss_{k}']), rtol=1e-4, atol=1e-5, err_msg=k)
+    for k in ('vote_xyz', 'vote_features'):
+        check_packed(z, f'g4e_d{k}', ep[k].grad, tol)
+    params = dict(net.named_parameters())
+    names = [str(n) for n in z['g4e_names']]
+    assert sum(n.startswith('detection.') for n in names) > 20
+    floor = 1e-3 * max(float(z[f'g4e_grad_{n}_sum'][2]) for n in names)
+    worst = {}
+    for n in names:
+        worst[n] = check_packed(z, f'g4e_grad_{n}', params[n].grad, tol, floor, n)
+    return worst
+
+
+def test_g4b_backbone_backward():
+    """CPU twin (torch modules + oracle ops).  Train-mode BatchNorm amplifies rounding differences between two
+    fp32 evaluation orders; 2e-3 of each tensor's largest gradient (measured worst: see the print)."""
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(GB)
+    net, cfg = build('train', 256)
+    worst = run_g4b(net, make_batch(2, 256, seed=356), z, torch.device('cpu'), cpu_ops, tol=2e-3)
+    print('g4b worst rel err', max(worst.values()), max(worst, key=worst.get))
+
+
+def test_g4e_eval_bn_step():
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(GB)
+    net, cfg = build('train', 256)
+    worst = run_g4e(net, make_batch(2, 256, seed=356), z, torch.device('cpu'), cpu_ops)
+    print('g4e worst rel err', max(worst.values()), max(worst, key=worst.get))
+
+
 def test_g4_train_step():
     from oracle.cpu_backend import cpu_ops
     from pose2room_amd.p2rnet.synthetic import make_batch

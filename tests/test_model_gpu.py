@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from tests import cases
-from tests.test_model_cpu import build, check_endpoints, run_g4, G
+from tests.test_model_cpu import build, check_endpoints, run_g4, run_g4b, run_g4e, G, GB
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,30 @@ def test_g4_train_step_gpu(dev):
     net, cfg = build('train', 256, device=dev)
     net = net.to(dev)
     run_g4(net, cfg, make_batch(2, 256, seed=356, device=dev), z, dev, contextlib.nullcontext)
+
+
+def test_g4b_backbone_backward_gpu(dev):
+    """ST-GCN backward on the HIP kernels (gcn dX/dW/dcoef, tconv dX/dW, BatchNorm backward, embedding MLPs)
+    against the REFERENCE's gradients: the reference's recorded seam gradients are back-propagated through
+    our backbone.  Train-mode BatchNorm amplifies fp32 rounding (measured x26 forward over the six blocks),
+    hence 2e-3 of each tensor's largest gradient; the eval-BatchNorm twin below holds 1e-4."""
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(GB)
+    net, cfg = build('train', 256, device=dev)
+    net = net.to(dev)
+    worst = run_g4b(net, make_batch(2, 256, seed=356, device=dev), z, dev, contextlib.nullcontext, tol=2e-3)
+    print('g4b gpu worst rel err', max(worst.values()), max(worst, key=worst.get))
+
+
+def test_g4e_eval_bn_step_gpu(dev):
+    """Whole step with BatchNorm on running statistics, end to end vs the reference at 1e-4: outputs, 10 losses,
+    and the gradients of ~130 parameters incl. gcn.conv / edge_importance / tcn.{0,2,3} of three blocks."""
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(GB)
+    net, cfg = build('train', 256, device=dev)
+    net = net.to(dev)
+    worst = run_g4e(net, make_batch(2, 256, seed=356, device=dev), z, dev, contextlib.nullcontext)
+    print('g4e gpu worst rel err', max(worst.values()), max(worst, key=worst.get))
 
 
 def test_smoke_train_step(dev):
