@@ -30,6 +30,9 @@ class GraphTables:
         self.nbr_r, self.gidx_r, self.Lk_r = gcn_tables.build(A, transpose=True)
         self.LkA_c = (ctypes.c_int * self.K)(*self.Lk_c)
         self.LkA_r = (ctypes.c_int * self.K)(*self.Lk_r)
+        # static work schedules of the second-generation kernels (unit = (plane, joint) with a non-empty list)
+        self.stream_c = torch.from_numpy(gcn_tables.build_stream(self.nbr_c, self.gidx_c, self.Lk_c)[0])
+        self.stream_r = torch.from_numpy(gcn_tables.build_stream(self.nbr_r, self.gidx_r, self.Lk_r)[0])
         self._dev = {}
 
     def on(self, device):
@@ -37,6 +40,7 @@ class GraphTables:
         if key not in self._dev:
             self._dev[key] = dict(nbr_c=self.nbr_c.to(device), gidx_c=self.gidx_c.to(device),
                                   nbr_r=self.nbr_r.to(device), gidx_r=self.gidx_r.to(device),
+                                  stream_c=self.stream_c.to(device), stream_r=self.stream_r.to(device),
                                   # 1 for a real list slot, 0 for padding (the adjacency gradient must also reach
                                   # real entries whose current coefficient happens to be zero)
                                   real_r=(self.gidx_r >= 0).to(torch.float32).to(device).contiguous())
@@ -54,6 +58,32 @@ def _gcn_forward(x, W, nbr, coef, LkA, bias_cv, tables, want_stats=False):
         _lib.check(_lib.lib().p2r_stgcn_gcn_forward(
             N, T, V, tables.K, LkA, _lib.ptr(x), _lib.ptr(W), _lib.ptr(nbr), _lib.ptr(coef),
             _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part), _lib.current_stream(x.device)), "stgcn_gcn_forward")
+    return (z, part) if want_stats else z
+
+
+def permute_planes(W3):
+    """W3 [K][64 rows][64 cols] -> the A-operand order of csrc/stgcn_gcn2.hip:
+    Wp[k][ph][m][16 g + r][s] = W3[k][16 m + r][16 ph + 4 s + g]  (one contiguous 1 KB per wave load)."""
+    K = W3.shape[0]
+    return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()     # (k, ph, m, g, r, s)
+
+
+def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False):
+    N, C, T, V = x.shape
+    z = torch.empty_like(x)
+    lib = _lib.lib()
+    part = None
+    ltot = coef.shape[0]
+    with torch.cuda.device(x.device):
+        st = _lib.current_stream(x.device)
+        if want_stats:
+            n = ctypes.c_int(0)
+            _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, None, None, None, None, None, None,
+                                                  None, ctypes.byref(n), st), "stgcn_gcn2_forward(size)")
+            part = torch.empty((n.value, C, 2), dtype=torch.float32, device=x.device)
+        _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
+                                              _lib.ptr(stream), _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part),
+                                              None, st), "stgcn_gcn2_forward")
     return (z, part) if want_stats else z
 
 

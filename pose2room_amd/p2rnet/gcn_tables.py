@@ -43,3 +43,179 @@ def coefficients(Aeff, gidx):
     flat = Aeff.reshape(-1)
     safe = gidx.clamp(min=0)
     return torch.where(gidx >= 0, flat[safe], torch.zeros((), dtype=Aeff.dtype, device=Aeff.device))
+
+
+STREAM_UMAX, STREAM_REC, STREAM_HDR = 80, 12, 16     # csrc/stgcn_gcn2.hip: G2_UMAX, G2_REC, G2_HDR
+
+
+def deal_joints(cost, n_waves, slots):
+    """Joints -> (wave, slot) owners with equal MFMA work.  cost[w] = number of non-empty (plane, w) units.
+    The matrix pipe is per SIMD and waves i, i + 4, i + 8, .. of a workgroup share one: the SIMDs are balanced
+    first (that is what bounds the kernel), then the waves of each SIMD."""
+    V = len(cost)
+
+    def deal(items, bins, cap):
+        """longest-processing-time-first into `bins` bins of at most `cap` items, then pairwise moves / swaps off
+        the fullest bin (the item cap defeats plain LPT)"""
+        own, ld = [[] for _ in range(bins)], [0] * bins
+        for w in sorted(items, key=lambda j: (-cost[j], j)):
+            i = min((c for c in range(bins) if len(own[c]) < cap), key=lambda c: (ld[c], c))
+            own[i].append(w)
+            ld[i] += int(cost[w])
+        improved = True
+        while improved:
+            improved = False
+            hi = max(range(bins), key=lambda c: ld[c])
+            for lo in sorted(range(bins), key=lambda c: ld[c]):
+                gap = ld[hi] - ld[lo]
+                if lo == hi or gap <= 1:
+                    continue
+                best = None
+                for a in own[hi]:
+                    if len(own[lo]) < cap and 0 < cost[a] < gap:
+                        best = (a, None)
+                        break
+                    for b_ in own[lo]:
+                        if 0 < cost[a] - cost[b_] < gap:
+                            best = (a, b_)
+                            break
+                    if best:
+                        break
+                if best:
+                    a, b_ = best
+                    own[hi].remove(a); own[lo].append(a)
+                    ld[hi] -= int(cost[a]); ld[lo] += int(cost[a])
+                    if b_ is not None:
+                        own[lo].remove(b_); own[hi].append(b_)
+                        ld[lo] -= int(cost[b_]); ld[hi] += int(cost[b_])
+                    improved = True
+                    break
+        return [sorted(o) for o in own]
+
+    assert n_waves % 4 == 0 and n_waves * slots >= V
+    per_simd = n_waves // 4
+    owner = [None] * n_waves
+    for sidx, group in enumerate(deal(range(V), 4, per_simd * slots)):
+        for j, part in enumerate(deal(group, per_simd, slots)):
+            owner[sidx + 4 * j] = part
+    return owner
+
+
+def deal_runs(cost, n_waves, slots):
+    """Joints -> (wave, slot) such that a wave's slots 0-3 hold one run of CONSECUTIVE joints and its slots 4-6 a
+    second one (the kernel stores the values of a run with one 16- or 12-byte store per lane).
+
+    The joints are cut into 2 * n_waves consecutive runs of three or four joints; every ordering of the run lengths
+    is tried, the runs are paired into waves (a four-run with a three-run) and the waves onto SIMDs (waves i and
+    i + 4 share one) heaviest with lightest; the split with the lightest busiest SIMD wins, ties broken by the
+    lightest busiest wave.  Returns per wave the list of 7 slot joints (-1 = unused slot)."""
+    import itertools
+    V = len(cost)
+    assert n_waves == 8 and slots == 7 and 3 * 16 <= V <= 4 * 8 + 3 * 8
+    n4 = V - 3 * 16                                   # runs of four (the other 16 - n4 runs have three joints)
+    best = None
+    for pos in itertools.combinations(range(16), n4):
+        lens = [4 if i in pos else 3 for i in range(16)]
+        if sum(1 for l in lens if l == 4) > 8:        # a wave has one 4-slot group only
+            continue
+        start, runs = 0, []
+        for l in lens:
+            runs.append((int(sum(cost[start:start + l])), start, l))
+            start += l
+        # slot group A takes the runs of four plus the heaviest runs of three, group B the rest
+        fours = sorted([r for r in runs if r[2] == 4])
+        threes = sorted([r for r in runs if r[2] == 3])
+        ga = sorted(fours + threes[len(threes) - (8 - len(fours)):])
+        gb = sorted(threes[:len(threes) - (8 - len(fours))])
+        waves = sorted(((ga[i][0] + gb[7 - i][0], ga[i], gb[7 - i]) for i in range(8)), key=lambda t: t[0])
+        simd = max(waves[i][0] + waves[7 - i][0] for i in range(4))
+        key = (simd, waves[7][0])
+        if best is None or key < best[0]:
+            best = (key, waves)
+    waves = best[1]
+    owner = [None] * n_waves
+    for i in range(4):
+        for widx, (_, ra, rb) in ((i, waves[7 - i]), (i + 4, waves[i])):
+            sl = [-1] * 7
+            for j in range(ra[2]):
+                sl[j] = ra[1] + j
+            for j in range(rb[2]):
+                sl[4 + j] = rb[1] + j
+            owner[widx] = sl
+    return owner
+
+
+def build_stream(nbr, gidx, Lk, n_waves=8, slots=7, joint_stride=1):
+    """Static per-wave work stream of the second-generation graph-conv kernel (csrc/stgcn_gcn2.hip).
+
+    A unit is (plane k, output joint w) with a non-empty neighbour list; a wave walks its units plane by plane.
+    One 12-int record per pass (lists longer than six entries take two passes):
+      [0]     slot | first-of-visit << 3 | (at most 2 entries) << 4 | plane << 8 | plane of the wave's next visit << 12
+              (15: wrap)
+      [1..3]  six 16-bit byte offsets  joint * joint_stride * 4  of the source joints
+      [4..9]  flat index into the coefficient table [ltot * V] per entry, -1 for padding (the kernel puts the
+              current coefficient there)
+    followed by a 16-int header: [0] records, [1] first plane, [2..8] joint of slot i or -1, [9] visits.
+    A visit is one pass over the slots in ascending order for one plane; long lists continue in an extra visit.
+    Returns (int32 [n_waves, 80 * 12 + 16], busiest SIMD's units, all units).
+    """
+    gidx = np.asarray(gidx)
+    nbr = np.asarray(nbr)
+    V = gidx.shape[1]
+    K = len(Lk)
+    assert K < 15 and slots <= 7 and V * joint_stride * 4 < 65536
+    lofs = np.concatenate([[0], np.cumsum(Lk)])
+    length = np.zeros((K, V), dtype=np.int64)           # real list length per (plane, joint)
+    for k in range(K):
+        length[k] = (gidx[lofs[k]:lofs[k + 1]] >= 0).sum(0)
+    cost = (length > 0).sum(0)
+    rec_cost = np.ceil(length / 6.0).astype(np.int64).sum(0)      # records per joint (lists > 6 entries: several)
+    owner = deal_runs(rec_cost, n_waves, slots)
+    load = np.array([sum(int(rec_cost[w]) for w in o if w >= 0) for o in owner])
+    simd_load = load.reshape(n_waves // 4, 4).sum(0)
+    out = np.zeros((n_waves, STREAM_UMAX * STREAM_REC + STREAM_HDR), dtype=np.int32)
+    for i in range(n_waves):
+        recs = []                                         # (plane, slot, first-of-visit, [(joint, table index)])
+        visits = 0
+        for k in range(K):
+            chunks = {}                                   # slot -> list of <= 6-entry chunks
+            for slot, w in enumerate(owner[i]):
+                if w < 0:
+                    continue
+                L = int(length[k, w])
+                ent = []
+                for j in range(L):
+                    row = int(lofs[k]) + j
+                    assert gidx[row, w] >= 0
+                    ent.append((int(nbr[row, w]), row * V + w))       # (source joint, coefficient table index)
+                if L:
+                    chunks[slot] = [ent[c:c + 6] for c in range(0, L, 6)]
+            depth = max((len(c) for c in chunks.values()), default=0)
+            for pass_i in range(depth):                   # a visit = one pass over the slots (ascending) of plane k
+                first = True
+                for slot in sorted(chunks):
+                    if pass_i < len(chunks[slot]):
+                        recs.append((k, slot, first, chunks[slot][pass_i]))
+                        first = False
+                visits += 1
+        assert len(recs) + 2 <= STREAM_UMAX, len(recs)
+        for u, (k, slot, first, ch) in enumerate(recs):
+            later = [kk for (kk, _, f, _) in recs[u + 1:] if f]
+            nk = later[0] if later else 15
+            base = u * STREAM_REC
+            out[i, base] = slot | (int(first) << 3) | (int(len(ch) <= 2) << 4) | (k << 8) | (nk << 12)
+            out[i, base + 4:base + 10] = -1
+            offs = [0] * 6
+            for j, (v, flat) in enumerate(ch):
+                out[i, base + 4 + j] = flat
+                offs[j] = v * joint_stride * 4
+            for q in range(3):
+                word = offs[2 * q] | (offs[2 * q + 1] << 16)
+                out[i, base + 1 + q] = word - (1 << 32) if word >= (1 << 31) else word
+        hdr = STREAM_UMAX * STREAM_REC
+        out[i, hdr] = len(recs)
+        out[i, hdr + 1] = recs[0][0] if recs else 0
+        out[i, hdr + 9] = visits
+        for slot, w in enumerate(owner[i]):
+            out[i, hdr + 2 + slot] = w
+    return out, owner, int(simd_load.max()), int(load.sum())

@@ -1,0 +1,47 @@
+"""Dev: time ablation builds of csrc/stgcn_gcn2.hip (tools/ubench/g2/g2_*.so; results of ablations are wrong by design)."""
+import os, sys, ctypes, glob
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pose2room_amd import _lib
+from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+from pose2room_amd.p2rnet import gcn_op, gcn_tables
+dev = torch.device('cuda:0')
+A = Graph().A
+K, V = A.shape[0], A.shape[1]
+tables = gcn_op.GraphTables(A)
+t = tables.on(dev)
+N, T = int(os.environ.get('N', 32)), int(os.environ.get('T', 1024))
+x = torch.randn(N, 64, T, V, device=dev)
+W = torch.randn(K, 64, 64, device=dev) / 8
+Wp = gcn_op.permute_planes(W)
+Aeff = torch.tensor(A, dtype=torch.float32, device=dev)
+z = torch.empty_like(x)
+here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ubench', 'g2')
+only = os.environ.get('ONLY')
+for path in sorted(glob.glob(os.path.join(here, 'g2_*.so'))):
+    name = os.path.basename(path)[3:-3]
+    if only and name not in only.split(','):
+        continue
+    lib = ctypes.CDLL(path)
+    nw, sl = (16, 4) if 'NW16' in name else (8, 7)
+    for form in ('col', 'row'):
+        nbr, gidx, Lk = (t['nbr_c'], t['gidx_c'], tables.Lk_c) if form == 'col' else (t['nbr_r'], t['gidx_r'], tables.Lk_r)
+        gid_cpu, nbr_cpu = (tables.gidx_c, tables.nbr_c) if form == 'col' else (tables.gidx_r, tables.nbr_r)
+        js = 16 if 'LAYOUT1' in name else 1
+        sched = torch.from_numpy(gcn_tables.build_stream(nbr_cpu, gid_cpu, Lk, nw, sl, js)[0]).to(dev)
+        coef = gcn_tables.coefficients(Aeff, gidx).contiguous()
+        part = torch.empty(256, 64, 2, device=dev)
+
+        def call():
+            rc = lib.p2r_stgcn_gcn2_forward(N, T, V, K, coef.shape[0], _lib.ptr(x), _lib.ptr(Wp),
+                                            _lib.ptr(coef), _lib.ptr(sched), None, _lib.ptr(z), _lib.ptr(part), None,
+                                            _lib.current_stream(dev))
+            assert rc == 0, rc
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            call()
+        e1.record(); e1.synchronize()
+        print(f'{name:28s} {form}: {e0.elapsed_time(e1) / 10:.3f} ms', flush=True)
