@@ -76,11 +76,8 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False):
     ltot = coef.shape[0]
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
-        if want_stats:
-            n = ctypes.c_int(0)
-            _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, None, None, None, None, None, None,
-                                                  None, ctypes.byref(n), st), "stgcn_gcn2_forward(size)")
-            part = torch.empty((n.value, C, 2), dtype=torch.float32, device=x.device)
+        if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
+            part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
         _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
                                               _lib.ptr(stream), _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part),
                                               None, st), "stgcn_gcn2_forward")
@@ -95,8 +92,12 @@ class _GraphConv(Function):
         t = tables.on(dev)
         x = x.contiguous()
         W = weight.contiguous()
-        out = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables,
-                           want_stats)
+        if tables.V == 53:      # second-generation kernel (csrc/stgcn_gcn2.hip)
+            out = _gcn2_forward(x, permute_planes(W.view(tables.K, 64, 64)), coef_c.contiguous(), t['stream_c'],
+                                bias_cv.contiguous(), tables, want_stats)
+        else:
+            out = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables,
+                               want_stats)
         ctx.save_for_backward(x, W, coef_c, coef_r)
         ctx.tables = tables
         if want_stats:
@@ -116,7 +117,11 @@ class _GraphConv(Function):
         dx = dW = dcoef_r = dbias = None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
-            dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
+            if tables.V == 53:
+                dx = _gcn2_forward(dz, permute_planes(W.view(K, C, C).transpose(1, 2)), coef_r.contiguous(),
+                                   t['stream_r'], None, tables)
+            else:
+                dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
         st = _lib.current_stream(dev)
         with torch.cuda.device(dev):
