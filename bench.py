@@ -11,10 +11,18 @@ backward (+ RCCL gradient all-reduce for N>1) -> AdamW step -> the 10-scalar
 reduce_dict / .item() of the reference's train_step (models/training.py:25-43).
 Workload = BASELINE.json configs[2]: bs=32 per GPU, T=1024, J=53 (weak scaling).
 
+The per-rank batch comes through the loader the epoch loops use (`P2RNet_dataloader`, with a
+`DistributedSampler` shard per rank when N > 1) over a seeded in-memory synthetic dataset.  `value` is
+measured with that batch resident in HBM (contract); the same K steps are then repeated with the
+reference's `to_device` inside the step -- the batch (6.5 MB per sample) crossing PCIe from pinned
+host memory each step, prefetched one step ahead on a side stream -- and reported under `h2d`.
+
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     -- the dominant kernel (gcn_fused_kernel) against the fp32 MFMA roof:
-                  FLOPs per launch / event-timed launch duration, HBM traffic from PMC;
-  step_roofline-- the whole step with the reference's algorithmic FLOPs;
+  step_ms      -- median / p10 / p90 of the per-step device time (events between steps, no host sync);
+  h2d          -- the same run with the batch copied host -> device every step (pinned, prefetched);
+  roofline     -- the dominant kernel (gcn2_kernel) against the fp32 MFMA roof: algorithmic FLOPs
+                  per launch / event-timed launch duration, executed-MFMA fraction, HBM traffic from PMC;
+  step_roofline-- the whole step with the reference's algorithmic FLOPs (and the executed-MFMA share);
   kernels      -- event-timed durations of the other HIP kernels at the P2RNet shapes;
   cpu_baseline -- the same host model on the host cores with the CPU oracle behind
                   the ops ("port"), on a bounded sample.
@@ -60,18 +68,28 @@ def build_trainer(device, frames, world):
     return Trainer(cfg, net, load_optimizer(cfg.config, net), device), cfg
 
 
-GCN_TRAFFIC_BYTES = 992719091    # profiles/r1_gcn_pmc_traffic.json (tools/pmc_traffic.sh): FETCH_SIZE (x2.0, calibrated) + WRITE_SIZE per launch
+def _profile_json(name):
+    """A measurement committed under profiles/ (written by the tools/pmc_*.sh scripts), or None."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 def dominant_kernel_roofline(device, batch, frames):
-    """The step's dominant kernel is gcn_fused_kernel (csrc/stgcn_gcn.hip): 12 launches per
-    step = 6 blocks x (forward: column lists, bias table, statistics epilogue) + 6 x (data
-    gradient: transposed planes, row lists).  Both launch configurations are timed at the bench
-    shape with events on the stream they are launched on; `ms_per_launch` is their mean, which is
-    what rocprofv3's per-kernel average over a bench run shows.  FLOPs per launch = what the
-    kernel executes for the reference's conv1x1 + graph einsum: dense 2*64*704 + sparse 2*64*971
-    per frame-joint column (the reference's dense formulation of the same op is 2*64*704 +
-    2*64*53*11 per column, reported as `reference_algorithmic_tflops`)."""
+    """The step's dominant kernel is gcn2_kernel (csrc/stgcn_gcn2.hip): 12 launches per step = 6 blocks x
+    (forward: column lists, bias table, statistics epilogue) + 6 x (data gradient: transposed planes, row
+    lists).  Both launch configurations are timed at the bench shape with events on the stream they are
+    launched on; `ms_per_launch` is their mean, which is what rocprofv3's per-kernel average over a bench
+    run shows.
+
+    `flops_per_launch` is the ALGORITHMIC work of the operator in its sparse-adjacency form, the same figure
+    as in round 1: per frame a dense 64 x (11*64) x 53 product (4.78 MFLOP) plus the
+    971-non-zero graph product (0.12 MFLOP).  The kernel does less than that: a (plane, joint) unit whose
+    neighbour list is empty is skipped (454 of 583 units forward, 369 data gradient), so `executed` reports
+    the MFMA FLOPs actually issued and the matrix-pipe fraction they correspond to.  The reference's dense
+    formulation of the same op (conv1x1 to 704 channels + einsum) is `reference_algorithmic_tflops`."""
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     from pose2room_amd.p2rnet import gcn_op, gcn_tables
     A = Graph().A
@@ -80,14 +98,15 @@ def dominant_kernel_roofline(device, batch, frames):
     t = tables.on(device)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 64, frames, V, generator=g).to(device)
-    W = (torch.randn(K * 64, 64, generator=g) / 8).to(device)
+    W = (torch.randn(K, 64, 64, generator=g) / 8).to(device)
+    Wp = gcn_op.permute_planes(W)
     At = torch.tensor(A, dtype=torch.float32, device=device)
     coef_c = gcn_tables.coefficients(At, t['gidx_c']).contiguous()
     coef_r = gcn_tables.coefficients(At, t['gidx_r']).contiguous()
     bias = torch.zeros(64, V, device=device)
     configs = {
-        'forward': lambda: gcn_op._gcn_forward(x, W, t['nbr_c'], coef_c, tables.LkA_c, bias, tables, True),
-        'data_gradient': lambda: gcn_op._gcn_forward(x, W, t['nbr_r'], coef_r, tables.LkA_r, None, tables),
+        'forward': lambda: gcn_op._gcn2_forward(x, Wp, coef_c, t['stream_c'], bias, tables, True),
+        'data_gradient': lambda: gcn_op._gcn2_forward(x, Wp, coef_r, t['stream_r'], None, tables),
     }
     stream = torch.cuda.current_stream(device)
     per = {}
@@ -107,15 +126,37 @@ def dominant_kernel_roofline(device, batch, frames):
     nnz = int((A != 0).sum())
     flops = (2.0 * 64 * 64 * K + 2.0 * 64 * nnz / V) * cols
     ref_flops = (2.0 * 64 * 64 * K + 2.0 * 64 * V * K) * cols
+    # MFMA work actually issued: one record of the work stream = 16 MFMAs per channel phase = 4 * 16 * 2048 FLOP
+    # per 16-frame tile (lists longer than six entries take two records)
+    hdr = gcn_tables.STREAM_UMAX * gcn_tables.STREAM_REC
+    recs = {'forward': int(tables.stream_c[:, hdr].sum()), 'data_gradient': int(tables.stream_r[:, hdr].sum())}
+    tiles = batch * ((frames + 15) // 16)
+    exec_flops = sum(recs.values()) / 2.0 * tiles * 4 * 16 * 2048.0
     tf = flops / ms / 1e9
+    traffic = _profile_json('r2_gcn2_pmc_traffic.json')
     scale = cols / float(32 * 1024 * 53)
-    return {'bound': 'mfma', 'kernel': 'gcn_fused_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
+    return {'bound': 'mfma', 'kernel': 'gcn2_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
             'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': int(GCN_TRAFFIC_BYTES * scale),
+            'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            'traffic': int(traffic['bytes_per_launch'] * scale) if traffic else None,
             'ms_per_launch': round(ms, 4), 'ms_forward': round(per['forward'], 4),
             'ms_data_gradient': round(per['data_gradient'], 4), 'flops_per_launch': flops,
+            'executed': {'mfma_flops_per_launch': exec_flops, 'tflops': round(exec_flops / ms / 1e9, 2),
+                         'frac': round(exec_flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         'units': '454 of 583 (plane, joint) units forward, 369 data gradient'},
             'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
             'reference_algorithmic_tflops': round(ref_flops / ms / 1e9, 2)}
+
+
+def step_executed_frac(ms_per_step, batch, frames):
+    """MFMA FLOPs the step's kernels actually issue (SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP/cycle/SIMD summed over one
+    step, profiles/r2_step_mfma.json from tools/pmc_step_mfma.sh at bs=32, T=1024; linear in batch * frames) over the
+    fp32 MFMA peak for the measured step time.  None when the profile is absent."""
+    prof = _profile_json('r2_step_mfma.json')
+    if not prof:
+        return None
+    flops = prof['mfma_busy_cycles_per_step'] * 64.0 * (batch * frames) / float(32 * 1024)
+    return round(flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
 
 
 def kernel_microbench(device):
@@ -225,9 +266,19 @@ def main():
             dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from pose2room_amd.p2rnet.synthetic import make_batch
     trainer, cfg = build_trainer(device, args.frames, world)
-    batch = make_batch(args.batch, args.frames, seed=1234, rank=rank, device=device)   # resident in HBM
+    # The batch arrives the way the reference's epoch loop gets it (models/p2rnet/dataloader.py:172-199): the loader
+    # over a seeded synthetic dataset, one DistributedSampler shard per rank.
+    from pose2room_amd.p2rnet.dataloader import P2RNet_dataloader, SyntheticPoseDataset
+    cfg.config['device']['distributed'] = world > 1
+    cfg.config['train']['batch_size'] = args.batch
+    dataset = SyntheticPoseDataset(args.batch * world, args.frames, seed=1234)
+    loader = P2RNet_dataloader(cfg, 'train', dataset=dataset)
+    if world > 1:
+        loader.sampler.set_epoch(0)
+    host_batch = next(iter(loader.dataloader))
+    assert host_batch['input_joints'].shape[0] == args.batch
+    batch = trainer.to_device(dict(host_batch))                      # resident in HBM
 
     def step():
         return trainer.train_step(dict(batch))
@@ -239,20 +290,57 @@ def main():
     # Collect now and freeze the survivors so later collections only look at the objects of the steps themselves.
     gc.collect()
     gc.freeze()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed(run_step):
+        """K steps between barrier + synchronize; also the per-step device time from events between the steps."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            out = run_step()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        q = lambda f: per_step[min(len(per_step) - 1, int(round(f * (len(per_step) - 1))))]
+        return dt, out, {'median': round(q(0.5), 3), 'p10': round(q(0.1), 3), 'p90': round(q(0.9), 3)}
+
+    elapsed, last, step_ms = timed(step)
+
+    # ---- the same steps with the reference's to_device inside the step (models/p2rnet/training.py:100-107): the batch
+    # sits in pinned host memory and is copied one step ahead on a side stream
+    pinned = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in host_batch.items()}
+    h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values() if torch.is_tensor(v))
+    copy_stream = torch.cuda.Stream(device)
+    state = {}
+
+    def prefetch():
+        with torch.cuda.stream(copy_stream):
+            state['next'] = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in pinned.items()}
+            state['ready'] = torch.cuda.Event()
+            state['ready'].record(copy_stream)
+
+    def step_h2d():
+        cur, ready = state['next'], state['ready']
+        torch.cuda.current_stream(device).wait_event(ready)
+        for v in cur.values():
+            if torch.is_tensor(v):
+                v.record_stream(torch.cuda.current_stream(device))
+        prefetch()                                   # the next batch crosses PCIe under this step's kernels
+        return trainer.train_step(cur)
+
+    prefetch()
+    step_h2d()
+    elapsed_h2d, _, step_ms_h2d = timed(step_h2d)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -262,16 +350,23 @@ def main():
             'metric': 'P2RNet train-step samples/sec (T=1024,J=53,bs=32)', 'value': round(sps, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'step_ms': step_ms,
+            'h2d': {'value': round(world * args.batch * args.steps / elapsed_h2d, 3), 'unit': 'samples/s',
+                    'ms_per_step': round(elapsed_h2d / args.steps * 1e3, 3), 'step_ms': step_ms_h2d,
+                    'bytes_per_step': h2d_bytes,
+                    'how': 'batch copied from pinned host memory every step (reference to_device), one step ahead on a '
+                           'side stream'},
             'config': {'workload': f'P2RNet full train step, bs={args.batch}/GPU, T={args.frames}, J=53, '
                                    f'seeds=512, proposals=128 (BASELINE configs[2])',
+                       'input': 'P2RNet_dataloader over SyntheticPoseDataset' + (' + DistributedSampler' if world > 1 else ''),
                        'global_batch': world * args.batch, 'frames': args.frames,
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
             'roofline': dominant_kernel_roofline(device, args.batch, args.frames),
             'step_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS * world,
                               'unit': 'TFLOP/s', 'frac': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
                               'scope': 'whole train step: algorithmic fwd+bwd FLOPs of the REFERENCE step '
-                                       f'({gflop_per_sample(args.frames)} GFLOP/sample, dense graph product) / step time'},
+                                       f'({gflop_per_sample(args.frames)} GFLOP/sample, dense graph product) / step time',
+                              'frac_executed': step_executed_frac(ms, args.batch, args.frames)},
         }
         if not args.no_microbench:
             line['kernels'] = kernel_microbench(device)

@@ -336,55 +336,97 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
     }
 
     // ---- epilogue: D[row = 16 m + 4 g + q][frame r] of joint sj[i]; statistics of the stored values.
-    // A wave's slots 0-3 hold CONSECUTIVE joints and so do its slots 4-6: the values of one (row, frame) of a run are
-    // contiguous in the (N,C,T,V) tensor and leave as one 16- or 12-byte store per lane (4-byte aligned) instead of
-    // scattered dwords.
     float *rs = rowstat + wave * 128;
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    if (stats_partial) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = 16 * m + 4 * g + q;
-        float s1 = 0.f, s2 = 0.f;
-        float *drow = zg + (size_t)row * row_stride + r * FS;
-        if (r < frames) {
-#ifndef G2X_NOSTORE
-          if (LAYOUT == 0 && SLOTS == 7) {
-            float *da = drow + sj[0];
-            if (na == 4) *reinterpret_cast<f4u *>(da) = f4u{acc[0][m][q], acc[1][m][q], acc[2][m][q], acc[3][m][q]};
-            else if (na == 3) *reinterpret_cast<f3u *>(da) = f3u{acc[0][m][q], acc[1][m][q], acc[2][m][q]};
-            else if (na == 2) *reinterpret_cast<f2u *>(da) = f2u{acc[0][m][q], acc[1][m][q]};
-            else if (na == 1) da[0] = acc[0][m][q];
-            float *db = drow + sj[4];
-            if (nb == 3) *reinterpret_cast<f3u *>(db) = f3u{acc[4][m][q], acc[5][m][q], acc[6][m][q]};
-            else if (nb == 2) *reinterpret_cast<f2u *>(db) = f2u{acc[4][m][q], acc[5][m][q]};
-            else if (nb == 1) db[0] = acc[4][m][q];
-          } else {
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+          if (r < frames) {
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i)
-              if (sj[i] >= 0) drow[sj[i] * VS] = acc[i][m][q];
+              if (sj[i] >= 0) {
+                const float v = acc[i][m][q];
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+              }
           }
-#endif
-#pragma unroll
-          for (int i = 0; i < SLOTS; ++i)
-            if (sj[i] >= 0) {
-              const float v = acc[i][m][q];
-              s1 += v;
-              s2 = fmaf(v, v, s2);
-            }
-        }
-        if (stats_partial) {
           s1 = p2r_row16_sum(s1);
           s2 = p2r_row16_sum(s2);
           if (r == 0) {             // slot owned by (wave, row): plain read-modify-write, deterministic
-            rs[2 * row] += s1;
-            rs[2 * row + 1] += s2;
+            rs[2 * (16 * m + 4 * g + q)] += s1;
+            rs[2 * (16 * m + 4 * g + q) + 1] += s2;
           }
         }
+    }
+#ifndef G2X_NOSTORE
+    if (LAYOUT == 0 && p.vec && frames == G2_F) {
+      // Full tiles leave through LDS: a (row, frame) line of the (N,C,T,V) tensor holds 16 consecutive joints, which
+      // belong to several waves -- stored from the accumulators it would go out as 12/16-byte fragments (measured:
+      // 2.4x the algorithmic HBM write bytes, partial lines).  The slice buffer of the last phase is free once every
+      // wave has finished it: 16 rows at a time are laid out there as the tensor has them and written as whole
+      // 16-byte-per-lane rows.  LDS-only waits in front of the barriers: the global stores stay in flight.
+      float *stg = lds + ((G2_NPH - 1) & 1) * BUF;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+          if (sj[i] >= 0) {
+            float *d0 = stg + 4 * g * RS + r * V + sj[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
+        const float4 *srow = reinterpret_cast<const float4 *>(stg);
+#pragma unroll
+        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+          const int e = it * NW * 64 + tid;
+          if (e < NV4) {
+            const int row = e / (RS / 4), c4 = e - row * (RS / 4);
+            zrow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
+    } else {
+      // ragged tiles / unaligned rows: straight from the accumulators.  A wave's slots 0-3 hold CONSECUTIVE joints
+      // and so do its slots 4-6, so the values of one (row, frame) of a run are contiguous and leave as one 16- or
+      // 12-byte store per lane (4-byte aligned).
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+      typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * m + 4 * g + q;
+          float *drow = zg + (size_t)row * row_stride + r * FS;
+          if (r < frames) {
+            if (LAYOUT == 0 && SLOTS == 7) {
+              float *da = drow + sj[0];
+              if (na == 4) *reinterpret_cast<f4u *>(da) = f4u{acc[0][m][q], acc[1][m][q], acc[2][m][q], acc[3][m][q]};
+              else if (na == 3) *reinterpret_cast<f3u *>(da) = f3u{acc[0][m][q], acc[1][m][q], acc[2][m][q]};
+              else if (na == 2) *reinterpret_cast<f2u *>(da) = f2u{acc[0][m][q], acc[1][m][q]};
+              else if (na == 1) da[0] = acc[0][m][q];
+              float *db = drow + sj[4];
+              if (nb == 3) *reinterpret_cast<f3u *>(db) = f3u{acc[4][m][q], acc[5][m][q], acc[6][m][q]};
+              else if (nb == 2) *reinterpret_cast<f2u *>(db) = f2u{acc[4][m][q], acc[5][m][q]};
+              else if (nb == 1) db[0] = acc[4][m][q];
+            } else {
+#pragma unroll
+              for (int i = 0; i < SLOTS; ++i)
+                if (sj[i] >= 0) drow[sj[i] * VS] = acc[i][m][q];
+            }
+          }
+        }
+    }
+#endif
   }
 
   if (stats_partial) {

@@ -206,12 +206,33 @@ def my_worker_init_fn(worker_id):
     np.random.seed(np.random.get_state()[1][0] + worker_id)
 
 
-def P2RNet_dataloader(cfg, mode='train'):
+class SyntheticPoseDataset(Dataset):
+    """Seeded synthetic samples with the reference loader's per-sample contract (dataloader.py:138-146), held in host
+    memory: what the benchmarks and the multi-rank tests feed through `P2RNet_dataloader` when no VirtualHome split is
+    mounted.  Sample i is `synthetic.make_batch(1, T, seed + i)` without its batch axis."""
+
+    def __init__(self, num_samples, num_frames, seed=1234):
+        from .synthetic import make_batch
+        self.samples = []
+        for i in range(num_samples):
+            b = make_batch(1, num_frames, seed=seed + i)
+            self.samples.append({k: (v[0] if torch.is_tensor(v) else v[0]) for k, v in b.items()})
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        return self.samples[idx]
+
+
+def P2RNet_dataloader(cfg, mode='train', dataset=None):
     """dataloader.py:172-199: DistributedSampler under DDP (one shard of the sample list per rank),
-    random / sequential sampling otherwise; returns the (dataloader, sampler) pair the epoch loops expect."""
+    random / sequential sampling otherwise; returns the (dataloader, sampler) pair the epoch loops expect.
+    `dataset` (not in the reference): use this map-style dataset instead of the VirtualHome split on disk."""
     if cfg.config['data']['dataset'] != 'virtualhome':
         raise NotImplementedError
-    dataset = P2RNet_VirtualHome(cfg, mode)
+    if dataset is None:
+        dataset = P2RNet_VirtualHome(cfg, mode)
     if cfg.config['device']['distributed']:
         sampler = DistributedSampler(dataset, shuffle=(mode == 'train'))
     elif mode == 'train':
