@@ -291,19 +291,37 @@ int p2r_embed3_weight_grad(int N, int L, const float *x, const float *dout, floa
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */
 int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream);
 
-/* ---- fused vote aggregation (inference) ----------------------------------------------- */
+/* ---- fused vote aggregation ------------------------------------------------------------ */
 
 /* replaces the chain ball_query -> group_points(features) -> [Conv2d 1x1 + ReLU] x2 ->
  * max over nsample of PointnetSAModuleVotes.forward (pointnet2_modules.py:220-259 with
- * mlp=[256,256,256], bn=False, use_xyz=False, pooling='max') in one launch, forward only.
+ * mlp=[256,256,256], bn=False, use_xyz=False, pooling='max') in one launch.
  * xyz (b,n,3), new_xyz (b,m,3), features (b,256,n), w1 (256,256), b1 (256), w2 (256,256),
  * b2 (256) -> idx (b,m,16) i32 (identical to p2r_ball_query), out (b,256,m) f32.
- * nsample must be 16 and C0 = C1 = C2 = 256. */
+ * nsample must be 16 and C0 = C1 = C2 = 256.
+ * Training: G, H (b,256,m,16) f32 and amax (b,256,m) u8 non-NULL -> the grouped features, the
+ * hidden activation and the arg-max sample of every (channel, ball) are saved for
+ * p2r_sa_votes_backward; all three NULL for inference. */
 int p2r_sa_votes_forward(int b, int n, int m, int nsample, float radius, int C0,
                          int C1, int C2, const float *xyz, const float *new_xyz,
                          const float *features, const float *w1, const float *b1,
                          const float *w2, const float *b2, int *idx, float *out,
-                         void *stream);
+                         float *G, float *H, unsigned char *amax, void *stream);
+
+/* autograd of the above (max-pool -> ReLU -> conv -> ReLU -> conv): dout, out (b,256,m);
+ * amax, H from the training forward; w2t / w1t (256,256) = transposed layer weights.
+ * Writes dZ2, dZ1 (pre-activation gradients of the two layers) and dG (gradient of the
+ * grouped features), all (b,256,m,16); dG goes to p2r_group_points_grad, (dZ2, H) and
+ * (dZ1, G) to p2r_gemm_nt_256 for the weight gradients. */
+int p2r_sa_votes_backward(int b, int m, int nsample, int C, const float *dout, const float *out,
+                          const unsigned char *amax, const float *H, const float *w2t,
+                          const float *w1t, float *dZ2, float *dZ1, float *dG, void *stream);
+
+/* weight gradient of a 256 -> 256 pointwise convolution: A, B (nb,256,L) ->
+ * partial [split][256][256], whose sum over the leading axis is sum_b A[b] . B[b]^T
+ * (split-K MFMA product, deterministic). */
+int p2r_gemm_nt_256(int nb, int L, int split, const float *A, const float *B, float *partial,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int G2_F = 16;            // frames per tile = columns of an MFMA n-tile
 constexpr int G2_CP = 16;           // channels per phase
 constexpr int G2_NPH = 4;           // phases (64 channels)
-constexpr int G2_MAXK = 16;
 
 struct G2Params {
   int T, V, K;

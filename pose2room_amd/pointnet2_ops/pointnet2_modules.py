@@ -136,7 +136,7 @@ class PointnetSAModuleVotes(nn.Module):
 
     def _can_fuse(self, features):
         from . import fused as fused_ops
-        return (self.fused and not torch.is_grad_enabled() and fused_ops.available() and self.npoint is not None
+        return (self.fused and fused_ops.available() and self.npoint is not None
                 and not self.bn and not self.use_xyz
                 and self.pooling == 'max' and not self.sample_uniformly and not self.ret_unique_cnt
                 and features is not None and features.is_cuda and len(self.mlp_module) == 4

@@ -188,3 +188,47 @@ def test_sa_votes_fused_forward(ext, oracle, dev, B, N, M, kind):
         nx2, nf2, inds2 = mod(xyz.to(dev), feats.to(dev))
     assert torch.equal(inds, inds2) and torch.equal(nx, nx2)
     torch.testing.assert_close(nf, nf2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,M,kind", [(2, 512, 128, "walk"), (1, 300, 37, "uniform"), (3, 64, 6, "lattice")])
+def test_sa_votes_fused_backward(ext, oracle, dev, B, N, M, kind):
+    """Training path of PointnetSAModuleVotes on the fused kernels (forward that saves G / H / arg-max, the two
+    transposed MFMA layers, split-K weight gradients, LDS-accumulated feature gradient) against (a) the unfused HIP
+    op chain through torch autograd and (b) the same module on the CPU oracle ops: indices exact, outputs 1e-4,
+    gradients 1e-3 of each tensor's largest entry.  'lattice' has duplicate neighbours in a ball (padding with the
+    first hit), i.e. exact ties in the max-pool: the gradient must go to the first maximum like max_pool2d's."""
+    import copy
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.pointnet2_ops.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(B * 5 + M)
+    mod_c = PointnetSAModuleVotes(npoint=M, radius=0.3, nsample=16, mlp=[256, 256, 256], use_xyz=False,
+                                  normalize_xyz=True, bn=False)
+    xyz = cases.cloud(B, N, 21, kind)
+    feats = torch.randn(B, 256, N)
+    go = torch.randn(B, 256, M)
+
+    def run(mod, device, ctx, fused):
+        mod.fused = fused
+        for p in mod.parameters():
+            p.grad = None
+        f = feats.detach().clone().to(device).requires_grad_(True)
+        with ctx():
+            nx, nf, inds = mod(xyz.to(device), f)
+            nf.backward(go.to(device))
+        return (nx.cpu(), nf.detach().cpu(), inds.cpu(), f.grad.cpu(),
+                {n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters()})
+
+    want = run(mod_c, 'cpu', cpu_ops, False)                       # oracle chain, torch autograd
+    mod_d = copy.deepcopy(mod_c).to(dev)
+    import contextlib
+    chain = run(mod_d, dev, contextlib.nullcontext, False)         # unfused HIP chain
+    got = run(mod_d, dev, contextlib.nullcontext, True)            # fused forward + backward
+    for ref in (want, chain):
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+        torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-4)
+        scale = ref[3].abs().max().item()
+        assert (got[3] - ref[3]).abs().max().item() <= 1e-3 * scale
+        for n in ref[4]:
+            scale = max(ref[4][n].abs().max().item(), 1e-6)
+            err = (got[4][n] - ref[4][n]).abs().max().item()
+            assert err <= 1e-3 * scale, f'{n}: {err:.3e} vs scale {scale:.3e}'
