@@ -126,6 +126,39 @@ int p2r_nn_distance_grad(int B, int N, int M, int C, const float *pc1,
                          const float *g1, const float *g2, float *grad_pc1,
                          float *grad_pc2, void *stream);
 
+/* ---- models/loss.py: BoxNetDetectionLoss -------------------------------- */
+
+/* replaces BoxNetDetectionLoss.__call__ (loss.py:152-189: vote loss :90-115, proposal/GT
+ * correspondence and objectness :117-150, centre / size / heading / class terms :42-88)
+ * -- some 150 torch micro-kernels forward -- by two launches.  seed_skeleton (B,S,J,3),
+ * vote_xyz (B,S,3) f32, seed_inds (B,S) i64, vote_label (B,T,J,9) f32, vote_label_mask
+ * (B,T,J) i64, agg_xyz / center / size (B,K,3) f32, heading (B,K,2) f64, obj_scores (B,K,2),
+ * sem_scores (B,K,NC) f32, center_label (B,G,3), box_mask (B,G), gt_size (B,G,3), gt_heading
+ * (B,G,2) f32, gt_cls (B,G) i64.
+ * out32 [12] f32: vote, objectness, center, size, sem_cls, pos_ratio, neg_ratio, obj_acc and the
+ * four normalisers' reciprocals; out64 [2] f64: heading_loss, total.  partial [B][12] f32 and
+ * partial64 [B] f64 are scratch; g_vote (B,S,3), g_obj (B,K,2), g_c1, g_c2, g_size (B,K,3),
+ * g_head (B,K,2) f64, g_sem (B,K,NC) receive the un-normalised gradient pieces. */
+int p2r_det_loss_forward(int B, int S, int J, int T, int K, int G, int NC, int j0, float near_thr,
+                         float far_thr, float w0, float w1, const float *seed_skeleton,
+                         const float *vote_xyz, const int64_t *seed_inds, const float *vote_label,
+                         const int64_t *vote_label_mask, const float *agg_xyz, const float *center,
+                         const float *size, const double *heading, const float *obj_scores,
+                         const float *sem_scores, const float *center_label, const float *box_mask,
+                         const float *gt_size, const float *gt_heading, const int64_t *gt_cls,
+                         float *partial, double *partial64, float *out32, double *out64, float *g_vote,
+                         float *g_obj, float *g_c1, float *g_c2, float *g_size, double *g_head,
+                         float *g_sem, void *stream);
+
+/* autograd of the above: coef [6] f64 on the device = gradient reaching (vote, objectness,
+ * center, size, heading, sem_cls) -> gradients of vote_xyz, objectness_scores, center, size,
+ * heading (f64) and sem_cls_scores, overwritten. */
+int p2r_det_loss_backward(int B, int S, int K, int NC, const double *coef, const float *out32,
+                          const float *g_vote, const float *g_obj, const float *g_c1, const float *g_c2,
+                          const float *g_size, const double *g_head, const float *g_sem, float *d_vote,
+                          float *d_obj, float *d_center, float *d_size, double *d_head, float *d_sem,
+                          void *stream);
+
 /* ---- net_utils/nms.py -------------------------------------------------- */
 
 /* replaces nms_3d_faster / nms_3d_faster_samecls (nms.py:41-77, :79-119),

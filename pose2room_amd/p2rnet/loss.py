@@ -1,14 +1,25 @@
 """Detection loss (mirror of the reference's models/loss.py:8-189).
 
 total = 10*vote + 5*objectness + 10*center + 10*size + 10*heading + sem_cls
-(loss.py:167).  All three `nn_distance` call sites run on the HIP kernel; the
-reference's per-sample Python loop for the proposal->GT assignment
-(loss.py:127-131) is one batched launch here: padded GT rows are pushed out to a
-far sentinel so the minimum runs over the valid prefix only, which yields the
-same dist1 / ind1 for every sample that has at least one GT box.
+(loss.py:167).  On GPU tensors the whole loss is one fused HIP op (csrc/det_loss.hip:
+forward = per-sample partial sums + a combine launch, backward = one launch) instead of
+~350 torch micro-kernels; `BoxNetDetectionLoss.composed` is the same computation as a
+composition of torch ops around `nn_distance` -- what CPU tensors run (the oracle-backed
+tests) and what the fused op is tested against.
+
+Padded ground-truth rows: the reference compacts per sample (`per_gt_center[per_mask > 0]`,
+loss.py:127-131) in a Python loop; here they are pushed out to a far sentinel so the minimum
+runs over the valid rows only.  `object_assignment` therefore indexes the UNcompacted GT rows,
+which equals the reference's index whenever `box_label_mask` is a prefix of ones -- the form
+the reference loader produces (dataloader.py:113-121) and `synthetic.make_batch` keeps.
 """
+import ctypes
+
 import torch
 from torch import nn
+from torch.autograd import Function
+
+from .. import _lib
 
 from ..net_utils.nn_distance import nn_distance, huber_loss
 from .registers import LOSSES
@@ -118,6 +129,11 @@ class BoxNetDetectionLoss(BaseLoss):
 
     # loss.py:152-189
     def __call__(self, est_data, gt_data, dataset_config):
+        if est_data['vote_xyz'].is_cuda:
+            return fused_detection_loss(est_data, gt_data, self.origin_joint_id)
+        return self.composed(est_data, gt_data, dataset_config)
+
+    def composed(self, est_data, gt_data, dataset_config):
         vote_loss = self.compute_vote_loss(est_data, gt_data)
         object_assignment, objectness_loss, objectness_label, objectness_mask = \
             self.compute_correspondence(est_data, gt_data)
@@ -137,3 +153,87 @@ class BoxNetDetectionLoss(BaseLoss):
                 'center_loss': center_loss, 'size_loss': size_loss, 'heading_loss': heading_loss,
                 'sem_cls_loss': sem_cls_loss, 'pos_ratio': pos_ratio, 'neg_ratio': neg_ratio,
                 'obj_acc': obj_acc}
+
+
+_NAMES32 = ('vote_loss', 'objectness_loss', 'center_loss', 'size_loss', 'sem_cls_loss', 'pos_ratio', 'neg_ratio',
+            'obj_acc')
+
+
+class _DetectionLoss(Function):
+    """Inputs with gradient: vote_xyz, objectness_scores, center, size, heading (f64), sem_cls_scores.
+    Outputs: the ten loss-dict entries in the reference's dtypes (`heading_loss`, `total` f64, the rest f32)."""
+
+    @staticmethod
+    def forward(ctx, vote_xyz, obj_scores, center, size, heading, sem_scores, seed_skeleton, seed_inds, agg_xyz,
+                gt, j0):
+        dev = vote_xyz.device
+        vote_xyz, obj_scores, center, size, heading, sem_scores = (
+            t.contiguous() for t in (vote_xyz, obj_scores, center, size, heading, sem_scores))
+        seed_skeleton, agg_xyz = seed_skeleton.contiguous(), agg_xyz.contiguous()
+        seed_inds = seed_inds.long().contiguous()
+        if heading.dtype != torch.float64:
+            raise RuntimeError("det_loss: heading must be float64 (the mixture head emits f64)")
+        B, S, J = seed_skeleton.shape[:3]
+        K, NC = center.shape[1], sem_scores.shape[2]
+        T, G = gt['vote_label'].shape[1], gt['center_label'].shape[1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        part, part64 = torch.empty((B, 12), **f32), torch.empty((B,), dtype=torch.float64, device=dev)
+        out32, out64 = torch.empty((12,), **f32), torch.empty((2,), dtype=torch.float64, device=dev)
+        g_vote = torch.empty((B, S, 3), **f32)
+        g_obj, g_c1, g_c2, g_size = (torch.empty((B, K, d), **f32) for d in (2, 3, 3, 3))
+        g_head = torch.empty((B, K, 2), dtype=torch.float64, device=dev)
+        g_sem = torch.empty((B, K, NC), **f32)
+        gts = [gt[k].contiguous() for k in ('vote_label', 'vote_label_mask', 'center_label', 'box_label_mask', 'size',
+                                            'heading', 'sem_cls_label')]
+        if gts[1].dtype != torch.int64 or gts[6].dtype != torch.int64:
+            raise RuntimeError("det_loss: vote_label_mask and sem_cls_label must be int64")
+        c = ctypes.c_float
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().p2r_det_loss_forward(
+                B, S, J, T, K, G, NC, int(j0), c(NEAR_THRESHOLD), c(FAR_THRESHOLD), c(OBJECTNESS_CLS_WEIGHTS[0]),
+                c(OBJECTNESS_CLS_WEIGHTS[1]), _lib.ptr(seed_skeleton), _lib.ptr(vote_xyz), _lib.ptr(seed_inds),
+                _lib.ptr(gts[0]), _lib.ptr(gts[1]), _lib.ptr(agg_xyz), _lib.ptr(center), _lib.ptr(size),
+                _lib.ptr(heading), _lib.ptr(obj_scores), _lib.ptr(sem_scores), _lib.ptr(gts[2]), _lib.ptr(gts[3]),
+                _lib.ptr(gts[4]), _lib.ptr(gts[5]), _lib.ptr(gts[6]), _lib.ptr(part), _lib.ptr(part64),
+                _lib.ptr(out32), _lib.ptr(out64), _lib.ptr(g_vote), _lib.ptr(g_obj), _lib.ptr(g_c1), _lib.ptr(g_c2),
+                _lib.ptr(g_size), _lib.ptr(g_head), _lib.ptr(g_sem), _lib.current_stream(dev)), "det_loss_forward")
+        ctx.save_for_backward(out32, g_vote, g_obj, g_c1, g_c2, g_size, g_head, g_sem)
+        ctx.dims = (B, S, K, NC)
+        outs = tuple(out32[i] for i in range(8)) + (out64[0], out64[1])
+        ctx.mark_non_differentiable(outs[5], outs[6], outs[7])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_vote, d_obj, d_center, d_size, d_sem, _pr, _nr, _acc, d_head, d_total):
+        out32, g_vote, g_obj, g_c1, g_c2, g_size, g_head, g_sem = ctx.saved_tensors
+        B, S, K, NC = ctx.dims
+        dev = out32.device
+        zero = torch.zeros((), dtype=torch.float64, device=dev)
+        dt = d_total.double() if d_total is not None else zero
+        terms = [(d_vote, 10.0), (d_obj, 5.0), (d_center, 10.0), (d_size, 10.0), (d_head, 10.0), (d_sem, 1.0)]
+        coef = torch.stack([dt * w + (g.double() if g is not None else zero) for g, w in terms]).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        o_vote = torch.empty((B, S, 3), **f32)
+        o_obj, o_center, o_size = (torch.empty((B, K, d), **f32) for d in (2, 3, 3))
+        o_head = torch.empty((B, K, 2), dtype=torch.float64, device=dev)
+        o_sem = torch.empty((B, K, NC), **f32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().p2r_det_loss_backward(
+                B, S, K, NC, _lib.ptr(coef), _lib.ptr(out32), _lib.ptr(g_vote), _lib.ptr(g_obj), _lib.ptr(g_c1),
+                _lib.ptr(g_c2), _lib.ptr(g_size), _lib.ptr(g_head), _lib.ptr(g_sem), _lib.ptr(o_vote), _lib.ptr(o_obj),
+                _lib.ptr(o_center), _lib.ptr(o_size), _lib.ptr(o_head), _lib.ptr(o_sem), _lib.current_stream(dev)),
+                "det_loss_backward")
+        return o_vote, o_obj, o_center, o_size, o_head, o_sem, None, None, None, None, None
+
+
+def fused_detection_loss(est_data, gt_data, origin_joint_id):
+    """The loss dict of BoxNetDetectionLoss.__call__ from the fused op (GPU tensors)."""
+    outs = _DetectionLoss.apply(est_data['vote_xyz'], est_data['objectness_scores'], est_data['center'],
+                                est_data['size'], est_data['heading'], est_data['sem_cls_scores'],
+                                est_data['seed_skeleton'].detach(), est_data['seed_inds'],
+                                est_data['aggregated_vote_xyz'].detach(), gt_data, origin_joint_id)
+    d = dict(zip(_NAMES32, outs[:8]))
+    return {'total': outs[9], 'vote_loss': d['vote_loss'], 'objectness_loss': d['objectness_loss'],
+            'center_loss': d['center_loss'], 'size_loss': d['size_loss'], 'heading_loss': outs[8],
+            'sem_cls_loss': d['sem_cls_loss'], 'pos_ratio': d['pos_ratio'], 'neg_ratio': d['neg_ratio'],
+            'obj_acc': d['obj_acc']}

@@ -1,0 +1,109 @@
+"""GPU: the fused detection loss (csrc/det_loss.hip) against the same loss composed of torch ops around the HIP
+nn_distance (BoxNetDetectionLoss.composed -- itself pinned to the reference by the G4 / G4e fixtures): the ten
+loss-dict entries with their dtypes, and the gradients of the six differentiable inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(B, S, K, T, seed, case):
+    g = torch.Generator().manual_seed(seed)
+    J, G, NC = 53, 10, 22
+    r = lambda *s: torch.randn(*s, generator=g)
+    est = {
+        'seed_skeleton': r(B, S, J, 3) * 0.4 + torch.tensor([0.0, 0.9, 0.0]),
+        'vote_xyz': r(B, S, 3),
+        'seed_inds': torch.sort(torch.randint(0, T, (B, S), generator=g), 1)[0],
+        'aggregated_vote_xyz': r(B, K, 3),
+        'center': r(B, K, 3),
+        'size': r(B, K, 3) * 0.5,
+        'heading': r(B, K, 2).double(),
+        'objectness_scores': r(B, K, 2),
+        'sem_cls_scores': r(B, K, NC),
+    }
+    n_obj = torch.randint(1, G + 1, (B,), generator=g)
+    mask = (torch.arange(G)[None] < n_obj[:, None]).float()
+    centre = r(B, G, 3)
+    if case == 'near':          # GT centres next to aggregated votes: positives exist
+        for b in range(B):
+            for j in range(int(n_obj[b])):
+                centre[b, j] = est['aggregated_vote_xyz'][b, (7 * j + 1) % K] + 0.05
+    elif case == 'none':        # every proposal far from every GT box: no positive, n_pos = 1e-6
+        centre = centre + 50.0
+    elif case == 'ties':        # duplicated GT centres and proposals exactly on them: exact ties in every arg-min
+        centre[:, 1] = centre[:, 0]
+        est['aggregated_vote_xyz'][:, :4] = centre[:, :1]
+        est['center'][:, 5] = est['center'][:, 4]
+        n_obj = torch.clamp(n_obj, min=2)
+        mask = (torch.arange(G)[None] < n_obj[:, None]).float()
+    elif case == 'single':
+        mask = torch.zeros(B, G); mask[:, 0] = 1
+        centre[:, 0] = est['aggregated_vote_xyz'][:, 3]
+    m3 = mask[..., None]
+    gt = {
+        'center_label': centre * m3, 'box_label_mask': mask, 'size': r(B, G, 3) * 0.5 * m3,
+        'heading': r(B, G, 2) * m3, 'sem_cls_label': torch.randint(0, NC, (B, G), generator=g) * mask.long(),
+        'vote_label': r(B, T, J, 9) * 0.5, 'vote_label_mask': (torch.rand(B, T, J, generator=g) < 0.6).long(),
+    }
+    if case == 'ties':          # equal GT votes: the first of the three must win, like torch.min / argmin
+        gt['vote_label'][..., 3:6] = gt['vote_label'][..., 0:3]
+    return est, gt
+
+
+@pytest.mark.parametrize("B,S,K,T,case", [(2, 512, 128, 64, 'near'), (3, 100, 37, 16, 'random'), (2, 64, 128, 32, 'none'),
+                                          (2, 300, 128, 40, 'ties'), (1, 512, 128, 8, 'single'), (32, 512, 128, 64, 'near')])
+def test_fused_detection_loss(dev, B, S, K, T, case):
+    from pose2room_amd.p2rnet import P2RConfig, default_config
+    from pose2room_amd.p2rnet.loss import BoxNetDetectionLoss
+    cfg = P2RConfig(default_config('train', data={'num_frames': T}), device=dev)
+    loss_fn = BoxNetDetectionLoss(1, dev, cfg)
+    est, gt = _scene(B, S, K, T, seed=B * 1000 + K + T, case=case)
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    diff = ['vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores']
+
+    def run(fused):
+        e = {k: v.clone().to(dev) for k, v in est.items()}
+        for k in diff:
+            e[k].requires_grad_(True)
+        out = loss_fn(e, gt, None) if fused else loss_fn.composed(e, gt, None)
+        out['total'].backward()
+        return out, {k: e[k].grad for k in diff}
+
+    want, gw = run(False)
+    got, gg = run(True)
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, (k, got[k].dtype, want[k].dtype)
+        np.testing.assert_allclose(got[k].item(), want[k].item(), rtol=2e-5, atol=1e-6, err_msg=k)
+    if case == 'none':
+        assert got['pos_ratio'].item() == 0 and got['size_loss'].item() == 0
+    else:
+        assert got['pos_ratio'].item() > 0
+    for k in diff:
+        assert gg[k].dtype == gw[k].dtype
+        scale = max(gw[k].abs().max().item(), 1e-12)
+        err = (gg[k] - gw[k]).abs().max().item()
+        assert err <= 2e-5 * scale, f'{k}: {err:.3e} vs scale {scale:.3e}'
+
+
+def test_fused_detection_loss_component_gradients(dev):
+    """Gradients requested for individual dict entries (not only `total`) arrive with their own weights."""
+    from pose2room_amd.p2rnet import P2RConfig, default_config
+    from pose2room_amd.p2rnet.loss import BoxNetDetectionLoss
+    cfg = P2RConfig(default_config('train', data={'num_frames': 32}), device=dev)
+    loss_fn = BoxNetDetectionLoss(1, dev, cfg)
+    est, gt = _scene(2, 128, 64, 32, seed=5, case='near')
+    gt = {k: v.to(dev) for k, v in gt.items()}
+
+    def run(fused):
+        e = {k: v.clone().to(dev) for k, v in est.items()}
+        for k in ('center', 'heading', 'size'):
+            e[k].requires_grad_(True)
+        out = loss_fn(e, gt, None) if fused else loss_fn.composed(e, gt, None)
+        (0.5 * out['center_loss'] + 3.0 * out['heading_loss'] + out['total']).backward()
+        return e
+    a, b = run(True), run(False)
+    for k in ('center', 'heading', 'size'):
+        torch.testing.assert_close(a[k].grad, b[k].grad, rtol=2e-5, atol=1e-7)
