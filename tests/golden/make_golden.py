@@ -87,6 +87,95 @@ def g2():
     print("g2", len(out), "arrays")
 
 
+# ---- decision margins of the CUDA-only `_ext` kernels (SURVEY 8c hazard (i)) -------------------------------------
+# The oracle and the HIP kernels evaluate (dx*dx + dy*dy) + dz*dz in source order without contraction; nvcc's default
+# -fmad=true may contract it to fma(dz, dz, fma(dy, dy, dx*dx)) or fma(dz, dz, fma(dx, dx, dy*dy)).  For every
+# random-cloud fixture the three arithmetic variants are replayed in numpy: the fixture records the smallest
+# relative gap at any decision (in float32 ulps) and whether both contracted variants reproduce the very same
+# indices.  Lattice / duplicate clouds have exact ties by construction and are excluded (their distances are exact
+# in all three variants).
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _sqdist(p, q, variant):
+    """p (..., 3), q (..., 3) float32 -> squared distance float32 in the given arithmetic variant."""
+    dx, dy, dz = (_f32(p[..., i] - q[..., i]) for i in range(3))
+    if variant == 'plain':
+        return _f32(_f32(_f32(dx * dx) + _f32(dy * dy)) + _f32(dz * dz))
+    fma = lambda a, b, c: _f32(a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64))
+    if variant == 'fma_xy':
+        return fma(dz, dz, fma(dy, dy, _f32(dx * dx)))
+    return fma(dz, dz, fma(dx, dx, _f32(dy * dy)))
+
+
+def _ulps(rel):
+    return float(rel / 2.0 ** -23)
+
+
+def ball_margin(new_xyz, xyz, radius, nsample):
+    new_xyz, xyz = new_xyz.numpy(), xyz.numpy()
+    r2 = np.float32(np.float32(radius) * np.float32(radius))
+    res = {}
+    for variant in ('plain', 'fma_xy', 'fma_yx'):
+        d2 = _sqdist(new_xyz[:, :, None, :], xyz[:, None, :, :], variant)           # (B, M, N)
+        hit = d2 < r2
+        B, M, N = hit.shape
+        idx = np.zeros((B, M, nsample), dtype=np.int32)
+        for b in range(B):
+            for j in range(M):
+                h = np.nonzero(hit[b, j])[0][:nsample]
+                if len(h):
+                    idx[b, j] = h[0]
+                    idx[b, j, :len(h)] = h
+        res[variant] = idx
+        if variant == 'plain':
+            gap = _ulps(np.min(np.abs(d2.astype(np.float64) - float(r2)) / float(r2)))
+    return res, gap
+
+
+def fps_margin(xyz, m):
+    xyz = xyz.numpy()
+    res, gap = {}, np.inf
+    for variant in ('plain', 'fma_xy', 'fma_yx'):
+        B, N, _ = xyz.shape
+        out = np.zeros((B, m), dtype=np.int32)
+        zero = np.zeros_like(xyz)
+        mag = _sqdist(xyz, zero, variant)            # x*x + y*y + z*z, the same contraction pattern
+        for b in range(B):
+            temp = np.full(N, 1e10, dtype=np.float32)
+            old = 0
+            for j in range(1, m):
+                d = _sqdist(xyz[b], xyz[b, old][None], variant)
+                d2 = np.minimum(d, temp)
+                temp = d2
+                cand = np.where(mag[b] <= 1e-3, np.float32(-1.0), d2)
+                old = int(np.argmax(cand))
+                out[b, j] = old
+                if variant == 'plain':
+                    top = np.partition(cand, -2)[-2:]
+                    if top[1] > 0:
+                        gap = min(gap, _ulps((float(top[1]) - float(top[0])) / float(top[1])))
+        res[variant] = out
+    return res, gap
+
+
+def nn3_margin(unknown, known):
+    unknown, known = unknown.numpy(), known.numpy()
+    res = {}
+    for variant in ('plain', 'fma_xy', 'fma_yx'):
+        d2 = _sqdist(unknown[:, :, None, :], known[:, None, :, :], variant)          # (B, n, m)
+        order = np.argsort(d2, axis=2, kind='stable')
+        res[variant] = order[:, :, :3].astype(np.int32)
+        if variant == 'plain' and d2.shape[2] > 3:
+            s = np.sort(d2, axis=2).astype(np.float64)
+            gap = _ulps(np.min((s[:, :, 3] - s[:, :, 2]) / np.maximum(s[:, :, 3], 1e-30)))
+    return res, gap
+
+
+RANDOM_KINDS = ('uniform', 'walk')
+
+
 def g6():
     E = cpu_ext.OracleExt
     out = {}
@@ -94,17 +183,34 @@ def g6():
         if n > 6000:
             continue  # keep the fixture small; large clouds are checked live against the oracle
         xyz = cases.cloud(b, n, seed, kind)
-        out[f"fps_{b}_{n}_{m}_{kind}_{seed}"] = E.furthest_point_sampling(xyz, m).numpy()
+        key = f"fps_{b}_{n}_{m}_{kind}_{seed}"
+        out[key] = E.furthest_point_sampling(xyz, m).numpy()
+        if kind in RANDOM_KINDS and n > 1:
+            res, gap = fps_margin(xyz, m)
+            assert np.array_equal(res['plain'], out[key]), key       # the numpy replay is the oracle's algorithm
+            out['margin_' + key] = np.array([gap, float(np.array_equal(res['fma_xy'], out[key]) and
+                                                        np.array_equal(res['fma_yx'], out[key]))])
     for (b, n, m, radius, nsample, kind, seed) in cases.BALL_CASES:
         xyz = cases.cloud(b, n, seed, kind)
         new_xyz = cases.centres_from(xyz, m, seed)
-        out[f"ball_{b}_{n}_{m}_{nsample}_{kind}_{seed}"] = E.ball_query(new_xyz, xyz, radius, nsample).numpy()
+        key = f"ball_{b}_{n}_{m}_{nsample}_{kind}_{seed}"
+        out[key] = E.ball_query(new_xyz, xyz, radius, nsample).numpy()
+        if kind in RANDOM_KINDS and n > 1:
+            res, gap = ball_margin(new_xyz, xyz, radius, nsample)
+            assert np.array_equal(res['plain'], out[key]), key
+            out['margin_' + key] = np.array([gap, float(np.array_equal(res['fma_xy'], out[key]) and
+                                                        np.array_equal(res['fma_yx'], out[key]))])
     for (b, n, m, kind, seed) in [(2, 512, 128, "uniform", 1), (2, 100, 2, "uniform", 2), (2, 300, 64, "lattice", 4)]:
         unknown = cases.cloud(b, n, seed, kind)
         known = cases.cloud(b, m, seed + 50, kind)
         d, i = E.three_nn(unknown, known)
         out[f"nn3_{b}_{n}_{m}_{kind}_{seed}_dist2"] = d.numpy()
         out[f"nn3_{b}_{n}_{m}_{kind}_{seed}_idx"] = i.numpy()
+        if kind in RANDOM_KINDS and m > 3:
+            res, gap = nn3_margin(unknown, known)
+            assert np.array_equal(res['plain'], i.numpy()), (b, n, m, kind)
+            out[f"margin_nn3_{b}_{n}_{m}_{kind}_{seed}"] = np.array([gap, float(np.array_equal(res['fma_xy'], i.numpy()) and
+                                                                                np.array_equal(res['fma_yx'], i.numpy()))])
     np.savez_compressed(os.path.join(HERE, "g6_ext_ops.npz"), **out)
     print("g6", len(out), "arrays")
 

@@ -154,3 +154,18 @@ def test_group_gather_roundtrip(oracle):
 def test_opt_n_threads(oracle):
     f = oracle.lib().p2r_oracle_opt_n_threads
     assert [f(w) for w in (1, 2, 3, 7, 8, 100, 511, 512, 513, 54272)] == [1, 2, 2, 4, 8, 64, 256, 512, 512, 512]
+
+
+def test_g6_decision_margins():
+    """SURVEY 8c hazard (i): the CUDA-only reference kernels may be built with FMA contraction (nvcc -fmad=true), the
+    oracle and the HIP kernels are not.  For every random-cloud fixture, make_golden.py replayed the algorithm in the
+    three arithmetic variants (source order, and both contractions of (dx*dx + dy*dy) + dz*dz): the smallest relative
+    gap at any decision (d2 vs r2 in ball_query, winner vs runner-up in FPS, 3rd vs 4th neighbour in three_nn) is
+    recorded in float32 ulps, together with whether the contracted variants give the very same indices."""
+    z = np.load(os.path.join(G, "g6_ext_ops.npz"))
+    keys = [k for k in z.files if k.startswith('margin_')]
+    assert len(keys) >= 12 and any('fps' in k for k in keys) and any('ball' in k for k in keys) and any('nn3' in k for k in keys)
+    for k in keys:
+        gap_ulps, same_under_fma = z[k]
+        assert gap_ulps > 4.0, (k, gap_ulps)           # no decision within rounding distance of flipping
+        assert same_under_fma == 1.0, k                 # and the FMA-contracted replays reproduce the fixture exactly

@@ -13,7 +13,7 @@ cc = glob.glob('/tmp/pm_step/**/*counter_collection.csv', recursive=True)[0]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for r in csv.DictReader(open(cc)):
     if r['Counter_Name'] != 'SQ_VALU_MFMA_BUSY_CYCLES': continue
-    k = r['Kernel_Name'].split('(')[0].split('<')[0].replace('void ', '').split('::')[-1].strip()[-60:] or r['Kernel_Name'][:60]
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0].split('::')[-1].strip()[-60:] or r['Kernel_Name'][:60]
     tot[k] += float(r['Counter_Value']); n[k] += 1
 steps = $STEPS
 total = sum(tot.values()) / steps
