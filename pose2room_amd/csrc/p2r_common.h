@@ -34,6 +34,21 @@ static inline int p2r_ref_opt_n_threads(int work_size) {
 
 static inline int p2r_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that launches on a
+// second GPU must set it there too.  `done` is one flag per device (zero-initialised static array owned by the call
+// site); racing threads at worst both set the attribute.
+#define P2R_MAX_DEVICES 64
+template <typename K>
+static inline hipError_t p2r_allow_big_lds(K kernel, unsigned char (&done)[P2R_MAX_DEVICES], int bytes = 160 * 1024) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < P2R_MAX_DEVICES && done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < P2R_MAX_DEVICES) done[dev] = 1;
+  return e;
+}
+
 // Squared distance exactly as the reference writes it:
 // (a-b)*(a-b) + (c-d)*(c-d) + (e-f)*(e-f), left-to-right, no contraction.
 __device__ __forceinline__ float p2r_sqdist(float ax, float ay, float az,

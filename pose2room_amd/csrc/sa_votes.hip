@@ -321,7 +321,8 @@ extern "C" int p2r_sa_votes_forward(int b, int n, int m, int nsample, float radi
   const int groups = (m + SA_BALLS - 1) / SA_BALLS;
   const size_t lds = 2 * (size_t)SA_C * SA_RS * sizeof(float);
   auto kern = train ? sa_votes_kernel<true> : sa_votes_kernel<false>;
-  hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static unsigned char lds_ok[2][P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(kern, lds_ok[train ? 1 : 0], (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(b * groups)), dim3(256), lds, p2r_stream(stream), n, m,
                      radius * radius, xyz, new_xyz, features, w1, b1, w2, b2, idx, out, G, H, amax);
@@ -340,8 +341,8 @@ extern "C" int p2r_sa_votes_backward(int b, int m, int nsample, int C, const flo
   if (b == 0 || m == 0) return P2R_OK;
   const int groups = (m + SA_BALLS - 1) / SA_BALLS;
   const size_t lds = 2 * (size_t)SA_C * SA_RS * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void *)sa_votes_backward_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(sa_votes_backward_kernel, lds_ok, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(sa_votes_backward_kernel, dim3((unsigned)(b * groups)), dim3(256), lds, p2r_stream(stream), m,
                      dout, out, amax, H, w2t, w1t, dZ2, dZ1, dG);

@@ -1,5 +1,9 @@
 // stgcn_gcn.hip -- fused spatial graph convolution of the ST-GCN backbone, gfx950.
 //
+// First generation.  The forward / data-gradient kernel below (gcn_fused_kernel) now serves joint counts other than
+// 53 only; for the P2RNet skeleton that op runs on stgcn_gcn2.hip.  The weight- and adjacency-gradient kernels
+// (gcn_dw_kernel, gcn_dcoef_kernel) are in use for every shape.
+//
 // Replaces ConvTemporalGraphical.forward (reference
 // models/p2rnet/modules/stgcn_layers.py:57-67):
 //     y = Conv2d_1x1(x)            (N,64,T,V) -> (N, K*64, T, V)   K = 11 partitions
@@ -17,7 +21,7 @@
 // the X tile in LDS once, and every lane builds its MFMA B-operand values
 // (X . A_k at its own column) on the fly from LDS with the per-column neighbour
 // list of plane k -- the aggregated tensor never exists in memory -- while
-// v_mfma_f32_32x32x2_f32 (exact fp32) accumulates Z over the K planes in AGPRs.
+// v_mfma_f32_16x16x4_f32 (exact fp32) accumulates Z over the K planes in registers.
 // W_k streams from L2 straight into A-operand VGPRs.  HBM traffic is the
 // algorithmic minimum: read X once, write Z once.
 //
@@ -285,12 +289,10 @@ extern "C" int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_h
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
   const size_t lds = (size_t)16 * GC_ROW4 * sizeof(float4) + (size_t)ofs * V * sizeof(int2) + (GC_THREADS / 64) * 2 * GC_C * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)gcn_fused_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  {
+    hipError_t e = p2r_allow_big_lds(gcn_fused_kernel, lds_ok);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(gcn_fused_kernel, dim3((unsigned)blocks), dim3(GC_THREADS), lds,
                      p2r_stream(stream), p, ofs, x, W, nbr, coef, bias_cv, z, stats_partial);
@@ -815,12 +817,10 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
   const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2) +
                      (size_t)K * (DW_MAXV / 4) * sizeof(int) + (size_t)GC_C * V * sizeof(float);
   if (lds > 160 * 1024 || row_len > 256) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)gcn_dw_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  {
+    hipError_t e = p2r_allow_big_lds(gcn_dw_kernel, lds_ok);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(gcn_dw_kernel, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
                      row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial, colsum_of_x);
@@ -840,12 +840,10 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
   if (N == 0) return P2R_OK;
   const size_t lds = (size_t)16 * DC_ROW4 * sizeof(float4) + (size_t)ltot * V * (sizeof(int2) + sizeof(float));
   if (lds > 160 * 1024) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)gcn_dcoef_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  {
+    hipError_t e = p2r_allow_big_lds(gcn_dcoef_kernel, lds_ok);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(gcn_dcoef_kernel, dim3(n_blocks), dim3(DC_THREADS), lds, p2r_stream(stream), p, N, ltot, x,
                      dz, Wt, nbr, coef, dcoef_partial);

@@ -482,7 +482,8 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
                      (size_t)G2_NW * 128 * sizeof(float) + (size_t)64 * V * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
   auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT>;
-  hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(kern, lds_ok);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, coef, stream, bias_cv,
                      z, stats_partial);

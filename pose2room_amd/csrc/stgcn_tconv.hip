@@ -336,12 +336,10 @@ static int tconv_forward_launch(int N, int T, int V, const float *x, const float
   if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
   const size_t lds = (size_t)TC_C * row_len * sizeof(float) + 2 * TC_C * sizeof(float);
   if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)tconv_fused_kernel<TAPS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  {
+    hipError_t e = p2r_allow_big_lds(tconv_fused_kernel<TAPS>, lds_ok);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const long long tiles = (long long)N * tiles_per_seq;
   if (tiles > 0x7fffffffLL) return P2R_EINVAL;
@@ -375,12 +373,10 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   while (row_h % 32 != 2) ++row_h;
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
   if (lds > 160 * 1024 || TW_F * V > 256 || (TW_F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)tconv_dw_kernel<TAPS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  {
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS>, lds_ok);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
                      row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);

@@ -47,13 +47,86 @@ def _scalars(loss_dict):
     return dict(zip(names, vals))
 
 
+def _split_by_optim_spec(net):
+    """Walk the module tree top-down: a module that carries a non-empty `optim_spec` (set from its
+    `model.<phase>.optimizer` override, network.py load_optim_spec) becomes one parameter group with that spec;
+    branches without any such module fall into the default group (models/optimizers.py:22-38)."""
+    groups, default = [], []
+
+    def owns_spec(m):
+        return any(getattr(c, 'optim_spec', None) or owns_spec(c) for c in m.children())
+
+    def visit(m):
+        for child in m.children():
+            if hasattr(child, 'optim_spec'):
+                groups.append((child, child.optim_spec))
+            elif owns_spec(child):
+                visit(child)
+            else:
+                default.append(child)
+    visit(net)
+    return groups, default
+
+
 def load_optimizer(config, net):
-    """AdamW with the yaml's Adam hyper-parameters (models/optimizers.py:90-94: the
-    reference builds AdamW for `method: Adam`)."""
+    """AdamW with the yaml's Adam hyper-parameters (models/optimizers.py:60-94: the reference builds AdamW for
+    `method: Adam`, SGD with momentum 0.9 otherwise), one parameter group per sub-module that brings its own
+    `optim_spec`, a default group for the rest."""
     spec = config['optimizer']
-    params = [p for p in net.parameters() if p.requires_grad]
-    return torch.optim.AdamW(params, lr=float(spec['lr']), betas=tuple(spec['betas']),
-                             eps=float(spec['eps']), weight_decay=float(spec['weight_decay']))
+    adam = spec.get('method', 'Adam') == 'Adam'
+    with_spec, default_modules = _split_by_optim_spec(net)
+    groups = []
+    for module, ms in with_spec:
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            continue
+        ms = ms or spec
+        g = {'params': params, 'lr': float(ms['lr'])}
+        if adam:
+            g.update(betas=tuple(ms['betas']), eps=float(ms['eps']), weight_decay=float(ms['weight_decay']))
+        groups.append(g)
+    rest = [p for m in default_modules for p in m.parameters() if p.requires_grad]
+    if rest:
+        groups.append({'params': rest})
+    if not groups:       # a bare module without children / specs
+        groups = [{'params': [p for p in net.parameters() if p.requires_grad]}]
+    if adam:
+        return torch.optim.AdamW(groups, lr=float(spec['lr']), betas=tuple(spec['betas']), eps=float(spec['eps']),
+                                 weight_decay=float(spec['weight_decay']))
+    return torch.optim.SGD(groups, lr=float(spec['lr']), momentum=0.9)
+
+
+class BNMomentumScheduler(object):
+    """Epoch-indexed BatchNorm momentum (models/optimizers.py:53-58,121-148):
+    momentum(e) = max(init * decay_rate ** (e // decay_step), floor), written into every BatchNorm1d/2d/3d of `model`.
+    The fused BatchNorm ops read `bn.momentum` at call time, so they follow the schedule like nn.BatchNorm does."""
+
+    def __init__(self, cfg, model, bn_lambda=None, last_epoch=-1):
+        if not isinstance(model, nn.Module):
+            raise RuntimeError("Class '{}' is not a PyTorch nn Module".format(type(model).__name__))
+        self.cfg, self.model = cfg, model
+        if bn_lambda is None:
+            b = cfg.config['bnscheduler']
+            bn_lambda = lambda it: max(b['bn_momentum_init'] * b['bn_decay_rate'] ** int(it / b['bn_decay_step']),
+                                       b['bn_momentum_max'])
+        self.lmbd = bn_lambda
+        self.step(last_epoch + 1)
+        self.last_epoch = last_epoch
+
+    def step(self, epoch=None):
+        epoch = self.last_epoch + 1 if epoch is None else epoch
+        self.last_epoch = epoch
+        momentum = self.lmbd(epoch)
+        for m in self.model.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.momentum = momentum
+
+    def show_momentum(self):
+        self.cfg.log_string('Current BN decay momentum :%f.' % (self.lmbd(self.last_epoch)))
+
+
+def load_bnm_scheduler(cfg, net, start_epoch):
+    return BNMomentumScheduler(cfg, net, last_epoch=start_epoch - 1)
 
 
 def load_scheduler(config, optimizer):

@@ -124,54 +124,67 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def _resample_unique(idx, nsample):
+    """Per ball: its distinct neighbour indices first (ascending), the remaining slots re-drawn uniformly from
+    them -- what the reference's `sample_uniformly` double loop does (pointnet2_utils.py:321-330), for all balls at
+    once.  Returns (idx int32 (B,P,S), number of distinct neighbours (B,P))."""
+    srt, _ = torch.sort(idx.long(), dim=2)
+    first = torch.ones_like(srt, dtype=torch.bool)
+    first[..., 1:] = srt[..., 1:] != srt[..., :-1]
+    count = first.sum(dim=2)                                              # (B,P) distinct neighbours
+    # stable partition: distinct values keep their ascending order in slots [0, count)
+    rank = torch.where(first, first.long().cumsum(dim=2) - 1, torch.full_like(srt, nsample))
+    order = torch.argsort(rank, dim=2, stable=True)
+    uniq = torch.gather(srt, 2, order)
+    draw = (torch.rand(idx.shape, device=idx.device) * count.unsqueeze(-1)).long().clamp_(max=nsample - 1)
+    slot = torch.arange(nsample, device=idx.device).view(1, 1, -1)
+    pick = torch.where(slot < count.unsqueeze(-1), slot.expand_as(draw), draw)
+    return torch.gather(uniq, 2, pick).to(idx.dtype), count
+
+
 class QueryAndGroup(nn.Module):
-    """Ball query around `new_xyz`, then group xyz offsets (optionally / radius)
-    and features.  Mirrors pointnet2_utils.py:279-361 including the optional
-    `sample_uniformly` re-sampling branch (:321-330) and the return conventions."""
+    """Neighbourhoods of `new_xyz` inside `xyz`: ball query, then the neighbours' offsets from their centre
+    (divided by the radius when `normalize_xyz`) and / or their features, stacked along the channel axis.
+    Same constructor, argument order and return conventions as pointnet2_utils.py:279-361."""
 
     def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False,
                  sample_uniformly=False, ret_unique_cnt=False):
         super().__init__()
+        if ret_unique_cnt and not sample_uniformly:
+            raise AssertionError("ret_unique_cnt needs sample_uniformly")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.ret_grouped_xyz = ret_grouped_xyz
         self.normalize_xyz = normalize_xyz
         self.sample_uniformly = sample_uniformly
         self.ret_unique_cnt = ret_unique_cnt
-        if self.ret_unique_cnt:
-            assert self.sample_uniformly
+
+    def _offsets(self, xyz, new_xyz, idx):
+        """(B,3,P,S): neighbour minus centre.  The subtraction / scaling happen in place on the freshly grouped tensor
+        (an op output, never a view of an input), as in the reference."""
+        local = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        local -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if self.normalize_xyz:
+            local /= self.radius
+        return local
 
     def forward(self, xyz, new_xyz, features=None):
+        if features is None and not self.use_xyz:
+            raise AssertionError("QueryAndGroup: no features given and use_xyz is off -- nothing to group")
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-
+        unique_cnt = None
         if self.sample_uniformly:
-            unique_cnt = torch.zeros((idx.shape[0], idx.shape[1]))
-            for ib in range(idx.shape[0]):
-                for ir in range(idx.shape[1]):
-                    uniq = torch.unique(idx[ib, ir, :])
-                    k = uniq.shape[0]
-                    unique_cnt[ib, ir] = k
-                    extra = torch.randint(0, k, (self.nsample - k,), dtype=torch.long)
-                    idx[ib, ir, :] = torch.cat((uniq, uniq[extra]))
+            idx, unique_cnt = _resample_unique(idx, self.nsample)
 
-        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,P,S)
-        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
-        if self.normalize_xyz:
-            grouped_xyz /= self.radius
-
-        if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz \
-                else grouped_features
+        # the offsets cost a grouping launch and two passes: only when somebody consumes them
+        local = self._offsets(xyz, new_xyz, idx) if (self.use_xyz or self.ret_grouped_xyz or features is None) else None
+        if features is None:
+            out = local
         else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
+            grouped = grouping_operation(features, idx)
+            out = torch.cat([local, grouped], dim=1) if self.use_xyz else grouped
 
-        ret = [new_features]
-        if self.ret_grouped_xyz:
-            ret.append(grouped_xyz)
-        if self.ret_unique_cnt:
-            ret.append(unique_cnt)
-        return ret[0] if len(ret) == 1 else tuple(ret)
+        extras = ([local] if self.ret_grouped_xyz else []) + ([unique_cnt] if self.ret_unique_cnt else [])
+        return (out, *extras) if extras else out
 
 
 class GroupAll(nn.Module):

@@ -251,3 +251,27 @@ def test_g4_backbone_train_mode_statistics():
         net(make_batch(2, 256, seed=356))
     np.testing.assert_allclose(net.state_dict()['backbone.st_gcn_networks.2.tcn.0.running_mean'].numpy(),
                                z['g4_bn_running_mean'], rtol=1e-3, atol=1e-4)
+
+
+def test_optimizer_groups_and_bn_momentum_schedule():
+    """models/optimizers.py:22-94,121-148: one AdamW parameter group per sub-module with its own optim_spec (per-phase
+    overrides from `model.<phase>.optimizer`), and the epoch-indexed BatchNorm momentum written into every BN layer."""
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.training import load_optimizer, BNMomentumScheduler
+    conf = default_config('train', data={'num_frames': 32})
+    conf['model']['detection']['optimizer'] = {'lr': 5e-4, 'weight_decay': 0.01}
+    net = METHODS.get('P2RNet')(P2RConfig(conf, device='cpu'))
+    opt = load_optimizer(conf, net)
+    assert len(opt.param_groups) == 3
+    assert sum(len(g['params']) for g in opt.param_groups) == len(list(net.parameters())) == 131
+    lrs = sorted(g['lr'] for g in opt.param_groups)
+    assert lrs == [5e-4, 1e-3, 1e-3]
+    det = [g for g in opt.param_groups if g['lr'] == 5e-4][0]
+    assert det['weight_decay'] == 0.01 and det['betas'] == (0.9, 0.999)
+    assert {id(p) for p in det['params']} == {id(p) for p in net.detection.parameters()}
+    sched = BNMomentumScheduler(None, net, bn_lambda=lambda e: max(0.5 * 0.5 ** (e // 2), 0.01))
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert bns and all(m.momentum == 0.5 for m in bns)
+    for _ in range(4):
+        sched.step()
+    assert all(m.momentum == 0.125 for m in bns) and sched.last_epoch == 4
