@@ -272,6 +272,6 @@ def test_optimizer_groups_and_bn_momentum_schedule():
     sched = BNMomentumScheduler(None, net, bn_lambda=lambda e: max(0.5 * 0.5 ** (e // 2), 0.01))
     bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
     assert bns and all(m.momentum == 0.5 for m in bns)
-    for _ in range(4):
+    for _ in range(4):          # the constructor applies epoch 0 and keeps last_epoch = -1, like the reference's
         sched.step()
-    assert all(m.momentum == 0.125 for m in bns) and sched.last_epoch == 4
+    assert all(m.momentum == 0.25 for m in bns) and sched.last_epoch == 3
