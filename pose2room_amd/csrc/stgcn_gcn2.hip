@@ -81,8 +81,8 @@ constexpr int G2_WSTRIDE = G2_UMAX * G2_REC + G2_HDR;
 template <int NW, int SLOTS, int VT, int LAYOUT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
     G2Params p, const float *__restrict__ x, const float *__restrict__ Wp, const float *__restrict__ coef,
-    const int *__restrict__ stream_g, const float *__restrict__ bias_cv, float *__restrict__ z,
-    float *__restrict__ stats_partial) {
+    const int *__restrict__ stream_g, const float *__restrict__ bias_cv, const float *__restrict__ addend,
+    float *__restrict__ z, float *__restrict__ stats_partial) {
   constexpr int V = VT;
   constexpr int RS = G2_F * V;                        // LDS row stride (floats): 848 == 16 (mod 32)
   constexpr int BUF = G2_CP * RS;                     // floats per phase buffer
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
     const int frames = min(G2_F, p.T - t0);
     const float *xg = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
     float *zg = z + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
+    const float *ag = addend ? addend + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * G2_F : 0;
@@ -381,13 +382,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
+        const float4 *arow = reinterpret_cast<const float4 *>(ag ? ag + (size_t)16 * m * row_stride : nullptr);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
 #pragma unroll
         for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
           const int e = it * NW * 64 + tid;
           if (e < NV4) {
             const int row = e / (RS / 4), c4 = e - row * (RS / 4);
-            zrow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+            float4 v = srow[e];
+            if (arow) {           // e.g. the gradient of the block's residual branch, added on the way out
+              const float4 ad = arow[(size_t)row * (row_stride / 4) + c4];
+              v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+            }
+            zrow[(size_t)row * (row_stride / 4) + c4] = v;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,6 +413,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
         for (int q = 0; q < 4; ++q) {
           const int row = 16 * m + 4 * g + q;
           float *drow = zg + (size_t)row * row_stride + r * FS;
+          if (r < frames && ag) {
+            const float *arow = ag + (size_t)row * row_stride + r * FS;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i)
+              if (sj[i] >= 0) acc[i][m][q] += arow[sj[i] * VS];
+          }
           if (r < frames) {
             if (LAYOUT == 0 && SLOTS == 7) {
               float *da = drow + sj[0];
@@ -459,12 +472,14 @@ constexpr int G2_NW = 8, G2_SLOTS = 7;
 //          built once per adjacency pattern by pose2room_amd/p2rnet/gcn_tables.build_stream).  Every joint must be
 //          owned by exactly one (wave, slot); the joints of a wave's slots 0-3 must be consecutive (unused slots last),
 //          and likewise those of its slots 4-6.
-//   bias_cv [64][V] or NULL.   stats_partial (optional) [n_partials][64][2].
+//   bias_cv [64][V] or NULL.   addend (N,64,T,V) or NULL: added to the result (z = op(x) + addend; the statistics
+//   are those of op(x)).   stats_partial (optional) [n_partials][64][2].
 // n_partials: number of workgroups = rows of stats_partial (returned through *n_partials; call with z == NULL to
 // query it).
 extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x, const float *Wp,
-                                      const float *coef, const int *stream, const float *bias_cv, float *z,
-                                      float *stats_partial, int *n_partials, void *stream_h) {
+                                      const float *coef, const int *stream, const float *bias_cv,
+                                      const float *addend, float *z, float *stats_partial, int *n_partials,
+                                      void *stream_h) {
   if (N < 0 || T <= 0 || V != 53 || K <= 0 || K >= 15 || ltot <= 0) return P2R_EINVAL;
   if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
@@ -486,7 +501,7 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
   hipError_t e = p2r_allow_big_lds(kern, lds_ok);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, coef, stream, bias_cv,
-                     z, stats_partial);
+                     addend, z, stats_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -68,7 +68,7 @@ def permute_planes(W3):
     return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()     # (k, ph, m, g, r, s)
 
 
-def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False):
+def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None):
     N, C, T, V = x.shape
     z = torch.empty_like(x)
     lib = _lib.lib()
@@ -79,14 +79,14 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False):
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
         _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
-                                              _lib.ptr(stream), _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part),
-                                              None, st), "stgcn_gcn2_forward")
+                                              _lib.ptr(stream), _lib.ptr(bias_cv), _lib.ptr(addend), _lib.ptr(z),
+                                              _lib.ptr(part), None, st), "stgcn_gcn2_forward")
     return (z, part) if want_stats else z
 
 
 class _GraphConv(Function):
     @staticmethod
-    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False):
+    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
@@ -100,13 +100,19 @@ class _GraphConv(Function):
                                want_stats)
         ctx.save_for_backward(x, W, coef_c, coef_r)
         ctx.tables = tables
+        ctx.n_out = 2 if want_stats else 1
         if want_stats:
             ctx.mark_non_differentiable(out[1])
+        if with_residual:
+            # the block's identity branch leaves through this op too, so that the backward sees the residual
+            # gradient next to dz and adds it inside the data-gradient kernel (no separate accumulation pass)
+            out = (out if want_stats else (out,)) + (x.view_as(x),)
         return out
 
     @staticmethod
-    def backward(ctx, dz, _dstats=None):
+    def backward(ctx, dz, *rest):
         x, W, coef_c, coef_r = ctx.saved_tensors
+        dres = rest[ctx.n_out - 1] if len(rest) >= ctx.n_out else None     # gradient of the identity branch, if any
         tables = ctx.tables
         dev = x.device
         t = tables.on(dev)
@@ -119,7 +125,8 @@ class _GraphConv(Function):
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
             if tables.V == 53:
                 dx = _gcn2_forward(dz, permute_planes(W.view(K, C, C).transpose(1, 2)), coef_r.contiguous(),
-                                   t['stream_r'], None, tables)
+                                   t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None)
+                dres = None
             else:
                 dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
@@ -154,7 +161,9 @@ class _GraphConv(Function):
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
-        return dx, dW, None, dcoef_r, dbias, None, None
+        if dres is not None:
+            dx = dres if dx is None else dx + dres
+        return dx, dW, None, dcoef_r, dbias, None, None, None
 
 
 def supported(x, weight, A):
@@ -163,8 +172,10 @@ def supported(x, weight, A):
             and A.shape[1] <= 64)
 
 
-def graph_conv(x, weight, bias, Aeff, tables, want_stats=False):
+def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False):
     """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
+    with_residual: additionally return x itself (last output) for the caller's identity branch; its gradient is then
+    added inside the data-gradient kernel.
     want_stats: also return the kernel's per-workgroup (sum, sum of squares) partials of z per channel
     ([P,64,2], see bn_op.moments) -- the batch statistics of the BatchNorm that consumes z."""
     K, V = tables.K, tables.V
@@ -176,4 +187,4 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False):
         bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
     else:
         bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
-    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats)
+    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual)

@@ -111,15 +111,17 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A, want_stats=False):
+    def forward(self, x, A, want_stats=False, with_residual=False):
         """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
-        following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv)."""
+        following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv).  with_residual (same
+        path): x itself comes back as the last element of the tuple, for the caller's identity branch."""
         assert A.size(0) == self.kernel_size
         if self.tables is not None and self.fused:
             from .. import gcn_op
             if gcn_op.supported(x, self.conv.weight, A):
-                return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats), A
-        assert not want_stats
+                return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats,
+                                         with_residual), A
+        assert not want_stats and not with_residual
         y = self.conv(x)
         n, kc, t, v = y.size()
         y = y.view(n, self.kernel_size, kc // self.kernel_size, t, v)
@@ -173,7 +175,12 @@ class st_gcn_block(nn.Module):
                      and gcn_op.supported(x, self.gcn.conv.weight, A) and bn_op.supported(x, self.tcn[0])
                      and tconv_op.supported(x, self.tcn[0], self.tcn[2]))
             if chain:
-                (z, zstats), A = self.gcn(x, A, want_stats=True)
+                if self.residual is _iden and x.requires_grad:
+                    # identity branch routed through the graph-conv op: its gradient is added inside the
+                    # data-gradient kernel instead of a separate accumulation pass over the activation
+                    (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True)
+                else:
+                    (z, zstats), A = self.gcn(x, A, want_stats=True)
                 u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True)
                 res_t = res if torch.is_tensor(res) else None
                 return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats), A
