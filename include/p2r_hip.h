@@ -204,13 +204,14 @@ int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
  * V must be 53.
  *   Wp     [K][4][4][64][4] f32: Wp[k][ph][m][16 g + r][s] = W_k[16 m + r][16 ph + 4 s + g]
  *   coef   [ltot][V] as above;  stream int32 [8][80 * 12 + 16]: the static per-wave work stream
- *   (record layout in csrc/stgcn_gcn2.hip; built by pose2room_amd/p2rnet/gcn_tables.build_stream)
+ *   (record layout in csrc/stgcn_gcn2.hip; built by pose2room_amd/p2rnet/gcn_tables.build_stream);
+ *   stream_work: scratch of the same size (the stream with the current coefficients, read by scalar loads)
  *   addend (N,64,T,V) or NULL is added to the result on the way out (the residual-branch gradient in the
  *   data-gradient launch); stats_partial [*n_partials][64][2] (optional); z == NULL queries *n_partials. */
 int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x, const float *Wp,
-                           const float *coef, const int *stream, const float *bias_cv,
-                           const float *addend, float *z, float *stats_partial, int *n_partials,
-                           void *stream_h);
+                           const float *coef, const int *stream, int *stream_work,
+                           const float *bias_cv, const float *addend, float *z, float *stats_partial,
+                           int *n_partials, void *stream_h);
 
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
  * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over

@@ -66,7 +66,8 @@ __device__ __forceinline__ void g2_dma4(const float *src, float *lds_dst) {
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
-// Work stream of a wave (LDS, built in the prologue from the caller's template): one 48-byte record per pass,
+// Work stream of a wave (global memory, written by gcn2_fill_stream_kernel from the caller's template and the current
+// coefficients right before the main kernel): one 48-byte record per pass,
 //   [0]      descriptor: bits 0-2 accumulator slot, bit 3 first record of a visit (switch the A operands), bit 4 at most two entries, bits 8-11
 //            plane, bits 12-15 plane of the wave's next visit (15: first plane of the next phase).  A visit is one
 //            pass over the slots in ascending order for one plane; a list longer than six entries continues in an
@@ -78,11 +79,22 @@ constexpr int G2_REC = 12;                   // dwords per record
 constexpr int G2_HDR = 16;                   // header dwords per wave: [0] records, [1] first plane, [2..8] slot joints, [9] visits
 constexpr int G2_WSTRIDE = G2_UMAX * G2_REC + G2_HDR;
 
+// template (table indices in the coefficient slots) + coefficient table -> work stream (values)
+__global__ void gcn2_fill_stream_kernel(int n, const int *__restrict__ templ, const float *__restrict__ coef,
+                                        int *__restrict__ work) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int v = templ[e];
+  const int q = e % G2_WSTRIDE, f = q % G2_REC;
+  if (q < G2_UMAX * G2_REC && f >= 4 && f < 10) v = v >= 0 ? __float_as_int(coef[v]) : 0;
+  work[e] = v;
+}
+
 template <int NW, int SLOTS, int VT, int LAYOUT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
-    G2Params p, const float *__restrict__ x, const float *__restrict__ Wp, const float *__restrict__ coef,
-    const int *__restrict__ stream_g, const float *__restrict__ bias_cv, const float *__restrict__ addend,
-    float *__restrict__ z, float *__restrict__ stats_partial) {
+    G2Params p, const float *__restrict__ x, const float *__restrict__ Wp, const int *__restrict__ stream_g,
+    const float *__restrict__ bias_cv, const float *__restrict__ addend, float *__restrict__ z,
+    float *__restrict__ stats_partial) {
   constexpr int V = VT;
   constexpr int RS = G2_F * V;                        // LDS row stride (floats): 848 == 16 (mod 32)
   constexpr int BUF = G2_CP * RS;                     // floats per phase buffer
@@ -90,8 +102,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   // LAYOUT 1 = [v][f] (16-frame blocks stored joint-major)
   constexpr int FS = LAYOUT == 0 ? V : 1, VS = LAYOUT == 0 ? 1 : G2_F;
   extern __shared__ float lds[];
-  int *stream = reinterpret_cast<int *>(lds + 2 * BUF);                   // [NW][G2_WSTRIDE]
-  float *rowstat = reinterpret_cast<float *>(stream + NW * G2_WSTRIDE);   // [NW][64][2]
+  float *rowstat = lds + 2 * BUF;                                         // [NW][64][2]
   float *bias_l = rowstat + NW * 128;                                     // [64][V] bias table (zeros without bias)
 
   const int tid = threadIdx.x;
@@ -99,13 +110,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
 
-  for (int e = tid; e < NW * G2_WSTRIDE; e += NW * 64) {
-    int v = stream_g[e];
-    const int w = e / G2_WSTRIDE, q = e - w * G2_WSTRIDE;
-    const int f = q % G2_REC;
-    if (q < G2_UMAX * G2_REC && f >= 4 && f < 10) v = v >= 0 ? __float_as_int(coef[v]) : 0;   // table index -> value
-    stream[e] = v;
-  }
   for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
   __syncthreads();
@@ -115,13 +119,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   // of a SIMD do not walk through their MFMA runs in lock-step
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(G2X_STATICPRIO);
 #endif
-  const int *ws = stream + wave * G2_WSTRIDE;
-  // Records are read through a pointer the compiler cannot prove wave-uniform: the values then stay in VGPRs instead
-  // of being moved to SGPRs with v_readfirstlane right behind the load (which would wait for the LDS in front of the
-  // MFMAs); only the descriptor word is made scalar, after the MFMAs.
-  int opaque_zero = 0;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-  const int4 *st = reinterpret_cast<const int4 *>(ws) + opaque_zero;   // 3 int4 per record
+  // The work stream is read with SCALAR loads (wave-uniform addresses into read-only global memory): descriptors,
+  // offsets and coefficients live in SGPRs.  On gfx950 fp32 MFMAs and VALU instructions of the two waves of a SIMD
+  // do not overlap (tools/ubench/mfma_valu_overlap.hip: their times add up; SALU, scalar loads and LDS reads do
+  // overlap), so every v_readfirstlane / v_mov / v_and taken out of the record handling is MFMA time won.
+  const int *ws = stream_g + wave * G2_WSTRIDE;
+  const int4 *st = reinterpret_cast<const int4 *>(ws);                 // 3 int4 per record
   const int *hdr = ws + G2_UMAX * G2_REC;
   const int nvisits = __builtin_amdgcn_readfirstlane(hdr[9]);
   const int plane0 = __builtin_amdgcn_readfirstlane(hdr[1]);
@@ -468,6 +471,7 @@ constexpr int G2_NW = 8, G2_SLOTS = 7;
 //          (W_k (64 x 64), row = output channel; pass W_k^T for the data gradient)
 //   coef   f32 [ltot][V]: coefficient table (values of A * importance at the list entries, as for
 //          p2r_stgcn_gcn_forward); `stream` refers to it by flat index
+//   stream_work int32 [8][80 * 12 + 16]: scratch, receives the stream with the coefficient values filled in
 //   stream int32 [8 waves][80 * 12 + 16]: the static per-wave work stream (record layout in the kernel source;
 //          built once per adjacency pattern by pose2room_amd/p2rnet/gcn_tables.build_stream).  Every joint must be
 //          owned by exactly one (wave, slot); the joints of a wave's slots 0-3 must be consecutive (unused slots last),
@@ -477,9 +481,9 @@ constexpr int G2_NW = 8, G2_SLOTS = 7;
 // n_partials: number of workgroups = rows of stats_partial (returned through *n_partials; call with z == NULL to
 // query it).
 extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x, const float *Wp,
-                                      const float *coef, const int *stream, const float *bias_cv,
-                                      const float *addend, float *z, float *stats_partial, int *n_partials,
-                                      void *stream_h) {
+                                      const float *coef, const int *stream, int *stream_work,
+                                      const float *bias_cv, const float *addend, float *z, float *stats_partial,
+                                      int *n_partials, void *stream_h) {
   if (N < 0 || T <= 0 || V != 53 || K <= 0 || K >= 15 || ltot <= 0) return P2R_EINVAL;
   if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
@@ -493,14 +497,19 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
   const int blocks = (int)(tiles < 256 ? tiles : 256);
   if (n_partials) *n_partials = blocks;
   if (!z) return P2R_OK;
-  const size_t lds = (size_t)2 * G2_CP * G2_F * V * sizeof(float) + (size_t)G2_NW * G2_WSTRIDE * sizeof(int) +
-                     (size_t)G2_NW * 128 * sizeof(float) + (size_t)64 * V * sizeof(float);
+  if (!stream_work) return P2R_EINVAL;
+  const size_t lds = (size_t)2 * G2_CP * G2_F * V * sizeof(float) + (size_t)G2_NW * 128 * sizeof(float) +
+                     (size_t)64 * V * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
   auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT>;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(kern, lds_ok);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, coef, stream, bias_cv,
+  const int n_stream = G2_NW * G2_WSTRIDE;
+  hipLaunchKernelGGL(gcn2_fill_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, p2r_stream(stream_h), n_stream,
+                     stream, coef, stream_work);
+  P2R_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, stream_work, bias_cv,
                      addend, z, stats_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;

@@ -78,9 +78,10 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
         st = _lib.current_stream(x.device)
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
+        work = torch.empty_like(stream)       # the stream with this call's coefficients (scalar-loaded by the kernel)
         _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
-                                              _lib.ptr(stream), _lib.ptr(bias_cv), _lib.ptr(addend), _lib.ptr(z),
-                                              _lib.ptr(part), None, st), "stgcn_gcn2_forward")
+                                              _lib.ptr(stream), _lib.ptr(work), _lib.ptr(bias_cv), _lib.ptr(addend),
+                                              _lib.ptr(z), _lib.ptr(part), None, st), "stgcn_gcn2_forward")
     return (z, part) if want_stats else z
 
 

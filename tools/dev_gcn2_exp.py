@@ -31,10 +31,11 @@ for path in sorted(glob.glob(os.path.join(here, 'g2_*.so'))):
         sched = torch.from_numpy(gcn_tables.build_stream(nbr_cpu, gid_cpu, Lk, nw, sl, js)[0]).to(dev)
         coef = gcn_tables.coefficients(Aeff, gidx).contiguous()
         part = torch.empty(256, 64, 2, device=dev)
+        work = torch.empty_like(sched)
 
         def call():
             rc = lib.p2r_stgcn_gcn2_forward(N, T, V, K, coef.shape[0], _lib.ptr(x), _lib.ptr(Wp),
-                                            _lib.ptr(coef), _lib.ptr(sched), None, None, _lib.ptr(z), _lib.ptr(part), None,
+                                            _lib.ptr(coef), _lib.ptr(sched), _lib.ptr(work), None, None, _lib.ptr(z), _lib.ptr(part), None,
                                             _lib.current_stream(dev))
             assert rc == 0, rc
         for _ in range(3):
