@@ -40,9 +40,11 @@ def test_fused_bn_act(dev, shape, with_res, train):
     torch.testing.assert_close(xn.grad, xr.grad, rtol=1e-4, atol=1e-5)
     if with_res:
         torch.testing.assert_close(rn.grad, rr.grad, rtol=1e-5, atol=1e-6)
+    # affine gradients in BOTH modes: in eval mode nn.BatchNorm2d still differentiates through weight / bias
+    # (frozen-statistics fine-tuning); the fused op must too
+    torch.testing.assert_close(bn_new.weight.grad, bn_ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bn_new.bias.grad, bn_ref.bias.grad, rtol=1e-4, atol=1e-4)
     if train:
-        torch.testing.assert_close(bn_new.weight.grad, bn_ref.weight.grad, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(bn_new.bias.grad, bn_ref.bias.grad, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(bn_new.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(bn_new.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
         assert int(bn_new.num_batches_tracked) == int(bn_ref.num_batches_tracked)

@@ -41,9 +41,9 @@ def test_bn_relu_tconv(dev, N, T, V, train):
     close(zn.grad, zr.grad, "dz", 1e-4)
     close(conv_new.weight.grad, conv_ref.weight.grad, "dW", 1e-4)
     close(conv_new.bias.grad, conv_ref.bias.grad, "dbias", 1e-4)
+    close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)      # also in eval mode (running statistics)
+    close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
     if train:
-        close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)
-        close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
 
@@ -83,9 +83,9 @@ def test_bn_relu_pointwise(dev, N, T, V, train):
     assert conv_new.weight.grad.shape == conv_new.weight.shape
     close(conv_new.weight.grad, conv_ref.weight.grad, "dW", 1e-4)
     close(conv_new.bias.grad, conv_ref.bias.grad, "dbias", 1e-4)
+    close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)      # also in eval mode (running statistics)
+    close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
     if train:
-        close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)
-        close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
 
