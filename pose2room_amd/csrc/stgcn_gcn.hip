@@ -656,12 +656,15 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
   // A tile's columns keep their joint across the persistent loop (column = frame * V + joint, tiles start at
   // whole frames), so the longest real list among a wave's 16 columns is fixed per (n-tile, plane); with the
   // coefficient table a plane that reaches none of the 16 columns gets length 0 and its MFMAs are skipped.
+  // Columns of a tile are taken JOINT-major (column c of the MFMA n-tiles = frame c % F of joint c / F, F = frames of
+  // a full tile): the 16 columns of an n-tile then span 3-4 joints instead of 16, and 33 % of the (plane, n-tile)
+  // units of the row lists are empty instead of 19 % (177 vs 213 units of 264 per tile).
   int tlen[GC_NT16];                       // plane k's value lives in lane k of the wave
 #pragma unroll
   for (int i = 0; i < GC_NT16; ++i) {
     const int col = (wave * GC_NT16 + i) * 16 + r;
     const bool in = col < p.F * p.V;
-    const int w = in ? col % p.V : 0;
+    const int w = in ? col / p.F : 0;
     int mine = 0;
     for (int k = 0; k < p.K; ++k) {
       int len = 0;
@@ -695,13 +698,13 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
 #pragma unroll
     for (int i = 0; i < GC_NT16; ++i) {
       const int col = (wave * GC_NT16 + i) * 16 + r;
-      valid[i] = col < ncols;
-      const int f = valid[i] ? col / p.V : 0;
-      wj[i] = valid[i] ? col - f * p.V : 0;
-      fbase[i] = f * p.V;
+      const int jn = col / p.F, f = col - jn * p.F;          // joint-major column -> (joint, frame)
+      valid[i] = jn < p.V && f * p.V < ncols;
+      wj[i] = valid[i] ? jn : 0;
+      fbase[i] = valid[i] ? f * p.V : 0;
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + col] : 0.f;
+        bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + fbase[i] + wj[i]] : 0.f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -751,11 +754,19 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         if (valid[i]) {
           const int2 *trow = tbl + lofs * p.V + wj[i];
           float *drow = dcs + lofs * p.V + wj[i];
-          if (L <= 1) dc_reduce<1>(h, xs4, g, trow, p.V, fbase[i], drow, L);
-          else if (L <= 3) dc_reduce<3>(h, xs4, g, trow, p.V, fbase[i], drow, L);
-          else if (L <= 5) dc_reduce<5>(h, xs4, g, trow, p.V, fbase[i], drow, L);
-          else if (L <= 8) dc_reduce<8>(h, xs4, g, trow, p.V, fbase[i], drow, L);
-          else dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow, L);
+          // exact capacities for the common lengths: a padded slot costs 4 LDS reads + 16 FMAs + a lane reduction,
+          // and VALU time is MFMA time lost on gfx950
+          switch (L) {
+            case 1: dc_reduce<1>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 2: dc_reduce<2>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 3: dc_reduce<3>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 4: dc_reduce<4>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 5: dc_reduce<5>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 6: dc_reduce<6>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            case 7:
+            case 8: dc_reduce<8>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+            default: dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
+          }
         }
       }
     }
