@@ -311,6 +311,15 @@ int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, c
                                 const float *shift, const float *dout, int n_blocks,
                                 float *dw_partial, float *dbias_partial, void *stream);
 
+/* Second generation of p2r_stgcn_tconv_forward for taps = 3, V = 53 (csrc/stgcn_tconv2.hip): MFMA n-tile = 16
+ * frames of one joint, channel phases double-buffered in LDS by LDS-DMA, persistent workgroups, input transform
+ * applied on the B operand.  Wp [3][4][4][64][4]: Wp[p][ph][m][16 g + r][s] = W[p][16 m + r][16 ph + 4 s + g].
+ * scale / shift both NULL = no input transform (the data-gradient launch, with flipped / transposed taps).
+ * stats_partial [*n_partials][64][2] (optional); out == NULL queries *n_partials. */
+int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                             const float *Wp, const float *bias, float *out, float *stats_partial,
+                             int *n_partials, void *stream);
+
 /* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
 
 /* pos_embed[0] / sk_feat[0] (stgcn.py:46-63): x (N,3,L), W [64][3], bias [64] or NULL ->

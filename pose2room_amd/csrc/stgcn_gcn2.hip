@@ -114,11 +114,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
   __syncthreads();
 
-#ifdef G2X_STATICPRIO
-  // waves i and i + 4 share a SIMD: the second half runs at a higher priority for the whole kernel, so the two waves
-  // of a SIMD do not walk through their MFMA runs in lock-step
-  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(G2X_STATICPRIO);
-#endif
   // The work stream is read with SCALAR loads (wave-uniform addresses into read-only global memory): descriptors,
   // offsets and coefficients live in SGPRs.  On gfx950 fp32 MFMAs and VALU instructions of the two waves of a SIMD
   // do not overlap (tools/ubench/mfma_valu_overlap.hip: their times add up; SALU, scalar loads and LDS reads do
@@ -297,13 +292,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
 #endif
             const int4 m0 = st[3 * u + 6], m1 = st[3 * u + 7], m2 = st[3 * u + 8];
             __builtin_amdgcn_sched_barrier(0);       // all LDS reads are requested before the MFMAs ...
-#ifdef G2X_DYNPRIO
-            // The two waves of a SIMD share its matrix pipe.  At equal priority the arbiter alternates them, they walk
-            // through their MFMA runs in lock-step and then both sit in their gather / control sections with the pipe
-            // idle.  A wave that owns the pipe for its whole run pushes its partner's run behind its own: the partner's
-            // non-MFMA section then falls under this run and vice versa.
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #ifndef G2X_NOMFMA
 #ifdef G2X_MFMAX
 #pragma unroll
@@ -316,9 +304,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
                 acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b_cur[s], acc[i][m], 0, 0, 0);
 #else
             acc[i][0][0] += b_cur[0] + b_cur[1] + b_cur[2] + b_cur[3] + a[0][0];
-#endif
-#ifdef G2X_DYNPRIO
-            __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);       // ... and consumed after them: no s_waitcnt inside the MFMA run
 #ifndef G2X_NOGATHER

@@ -22,11 +22,27 @@ from . import bn_op
 _N_BLOCKS = 256
 
 
+def _permute_taps(W3):
+    """W3 [taps][64 rows][64 cols] -> the A-operand order of csrc/stgcn_tconv2.hip (same as gcn_op.permute_planes)."""
+    K = W3.shape[0]
+    return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()
+
+
 def _tconv(x, scale, shift, W3, bias, want_stats=False):
     N, C, T, V = x.shape
     out = torch.empty_like(x)
     lib = _lib.lib()
     part = None
+    if W3.shape[0] == 3 and V == 53:          # second-generation kernel
+        Wp = _permute_taps(W3)
+        with torch.cuda.device(x.device):
+            st = _lib.current_stream(x.device)
+            if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
+                part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
+            _lib.check(lib.p2r_stgcn_tconv2_forward(N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
+                                                    _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None, st),
+                       "stgcn_tconv2_forward")
+        return (out, part) if want_stats else out
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
         if want_stats:      # one (sum, sum of squares) partial per persistent workgroup: ask how many
