@@ -14,13 +14,13 @@
 //   * the 64 input channels in four phases of 16; a phase's slice = 16 rows x 16 frames x 53 joints (16-byte LDS-DMA
 //     pieces, the tensor's own order) plus the two halo frames t0-1 and t0+16 (4-byte pieces) in one of two LDS
 //     buffers, copied under the previous phase's MFMAs;
-//   * BatchNorm affine + ReLU are applied to the B operand as it is read (2 VALU per value; the normalised
-//     activation never exists in memory).  Positions outside the sequence hold NaN in that mode -- max(NaN, 0) = 0
-//     is exactly the zero padding of the convolution -- and 0 in the plain mode;
+//   * BatchNorm affine + ReLU are applied in place to each slice when it has landed in LDS (the normalised
+//     activation never exists in HBM).  Positions outside the sequence hold NaN in that mode -- max(NaN, 0) = 0 is
+//     exactly the zero padding of the convolution -- and 0 in the plain mode;
 //   * persistent workgroups; a wave owns up to 7 consecutive joints x 64 rows x 16 frames of accumulators across the
 //     phases; the tile leaves through LDS as whole rows; the epilogue also emits per-channel (sum, sum of squares).
 // On gfx950 fp32 MFMAs and VALU work of the co-resident wave do not overlap, which is why the per-record work here is
-// one v_add + (with the transform) eight more VALU instructions per 16 MFMAs, and nothing else.
+// four LDS reads at immediate offsets and nothing else.
 #include "p2r_common.h"
 
 namespace {
@@ -202,13 +202,28 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
       const float *src = same ? xg + (size_t)(ph + 1) * T2_CP * row_stride : nxg;
       const int sfr = same ? frames : nfr;
       const bool slo = same ? t0 > 0 : nt0 > 0, shi = same ? t0 + T2_F < p.T : nt0 + T2_F < p.T;
-      float sc[4], sh[4];
       if (XFORM) {
+        // BatchNorm affine + ReLU once per element, in place in the slice that has just landed (VALU work is matrix-pipe
+        // time on gfx950: transforming the B operand as it is read costs 8 VALU per 16 MFMAs, three times per element)
+        float *cur = lds + (ph & 1) * BUF;
+        float4 *cur4 = reinterpret_cast<float4 *>(cur);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sc[s] = aff[2 * (T2_CP * ph + 4 * s + g)];
-          sh[s] = aff[2 * (T2_CP * ph + 4 * s + g) + 1];
+        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+          const int e = it * NW * 64 + tid;
+          if (e < NV4) {
+            const int ch = T2_CP * ph + e / (RS / 4);
+            const float sc = aff[2 * ch], sh = aff[2 * ch + 1];
+            float4 v = cur4[e];
+            v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+            cur4[e] = v;
+          }
         }
+        for (int e = tid; e < HALO; e += NW * 64) {
+          const int ch = T2_CP * ph + e / HRS;
+          cur[MAIN + e] = fmaxf(fmaf(cur[MAIN + e], aff[2 * ch], aff[2 * ch + 1]), 0.f);
+        }
+        __syncthreads();
       }
 
 #pragma unroll 1
@@ -232,11 +247,7 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
           if (i < nslots) {
-            float b[4] = {b0[i], b1[i], b2[i], b3[i]};
-            if (XFORM) {
-#pragma unroll
-              for (int s = 0; s < 4; ++s) b[s] = fmaxf(fmaf(b[s], sc[s], sh[s]), 0.f);
-            }
+            const float b[4] = {b0[i], b1[i], b2[i], b3[i]};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
