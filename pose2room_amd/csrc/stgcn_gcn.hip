@@ -526,17 +526,25 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
         }
 #else
         // tighter register budget: passes of at most three list entries
+#ifndef DWX_NOGATHER
         for (int j0 = 0; j0 < Lr; j0 += 3) {
           const int rem = Lr - j0;
           if (rem <= 1) dw_plane<1>(trow + j0 * p.V, p.V, xrow, p.V, live, rem, b);
           else dw_plane<3>(trow + j0 * p.V, p.V, xrow, p.V, live, rem < 3 ? rem : 3, b);
         }
+#else
+        b[0] = b[1] = b[2] = b[3] = a[0][0];
 #endif
+#endif
+#ifndef DWX_NOMFMA
 #pragma unroll
         for (int f = 0; f < DW_F; ++f)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
             acc[kk][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f], b[f], acc[kk][m], 0, 0, 0);
+#else
+        acc[kk][0][0] += b[0] + b[1] + b[2] + b[3] + a[0][0] + a[1][1] + a[2][2] + a[3][3];
+#endif
 
       }
     }

@@ -14,7 +14,7 @@ def _reference(x, weight, bias, Aeff):
     return torch.einsum('nkctv,kvw->nctw', y.view(n, K, kc // K, t, v), Aeff)
 
 
-@pytest.mark.parametrize("N,T", [(1, 1), (2, 7), (1, 20), (3, 33), (2, 130)])
+@pytest.mark.parametrize("N,T", [(1, 1), (2, 7), (1, 20), (3, 33), (2, 130), (5, 1000)])   # (5,1000): 315 tiles > 256 persistent workgroups, ragged last tile
 def test_graph_conv_forward_backward(dev, N, T):
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     from pose2room_amd.p2rnet import gcn_op

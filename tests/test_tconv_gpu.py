@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 53), (3, 9, 53), (2, 130, 53), (2, 17, 25)])
+@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 53), (3, 9, 53), (2, 130, 53), (2, 17, 25), (5, 1000, 53), (2, 64, 53)])
 @pytest.mark.parametrize("train", [True, False])
 def test_bn_relu_tconv(dev, N, T, V, train):
     from pose2room_amd.p2rnet import tconv_op
@@ -25,24 +25,34 @@ def test_bn_relu_tconv(dev, N, T, V, train):
     go = torch.randn(N, 64, T, V, device=dev)
 
     zr = z.double().clone().requires_grad_(True)
-    ur = conv_ref(torch.relu(bn_ref(zr)))
+    pre = bn_ref(zr)
+    ur = conv_ref(torch.relu(pre))
     ur.backward(go.double())
     zn = z.clone().requires_grad_(True)
     assert tconv_op.supported(zn, bn_new, conv_new)
     un = tconv_op.bn_relu_tconv(zn, bn_new, conv_new)
     un.backward(go)
 
-    def close(a, b, what, tol=3e-5):
+    def close(a, b, what, tol=3e-5, where=None):
         scale = b.abs().max().item() + 1e-12
-        err = (a.double() - b.double()).abs().max().item()
+        err = (a.double() - b.double()).abs()
+        if where is not None:
+            err = err * where
+        err = err.max().item()
         assert err <= tol * scale, f"{what}: {err:.3e} vs {scale:.3e}"
 
     close(un, ur, "u")
-    close(zn.grad, zr.grad, "dz", 1e-4)
+    # the ReLU gate of an element whose pre-activation is within rounding of zero may open in fp32 and not in fp64
+    # (one of 17M elements at the largest shape): such elements are left out of the data-gradient comparison
+    decided = (pre.detach().abs() > 1e-5).double()
+    assert decided.mean().item() > 0.9999
+    close(zn.grad, zr.grad, "dz", 1e-4, where=decided)
     close(conv_new.weight.grad, conv_ref.weight.grad, "dW", 1e-4)
     close(conv_new.bias.grad, conv_ref.bias.grad, "dbias", 1e-4)
-    close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)      # also in eval mode (running statistics)
-    close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", 1e-4)
+    # an undecided gate (see above) moves its whole gradient term in or out of the per-channel sums
+    aff_tol = 1e-4 if decided.min().item() == 1.0 else 5e-4
+    close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", aff_tol)   # also in eval mode (running statistics)
+    close(bn_new.bias.grad, bn_ref.bias.grad, "dbeta", aff_tol)
     if train:
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
