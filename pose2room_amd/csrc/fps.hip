@@ -163,6 +163,121 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, int L,
   }
 }
 
+// Cooperative FPS for clouds beyond one workgroup's register file: G
+// workgroups per cloud (b*G <= 256, so every workgroup is resident), each
+// holding a contiguous slice in VGPRs.  A round is the register-resident round
+// above plus one exchange of the G slice winners through global memory:
+// workgroup g publishes {distance bits | round} and {~key | round} as two
+// 8-byte granules with agent-scope stores, and its first wave polls the 2*G
+// granules of the cloud (one load instruction) until every tag shows the
+// current round -- data-tagged, so no fences and no counters.  Slots alternate
+// by round parity; the host zeroes them before the launch (round tags start at
+// 1).  The sequential chain per round is one LDS barrier, one publish/poll
+// (~2 us) and one LDS broadcast, instead of n/1024 dependent L2 sweeps.
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int G, int S, int n, int m, int L,
+                                                        const float *__restrict__ dataset,
+                                                        unsigned long long *__restrict__ slots,
+                                                        int *__restrict__ idxs) {
+  constexpr int T = 1024, W = 16;
+  __shared__ long long s_slot[2][W];
+  __shared__ int s_old[2];
+  const int tid = threadIdx.x;
+  const int cloud = blockIdx.x % b, g = blockIdx.x / b;  // a cloud's workgroups share an XCD when b | 8
+  const float *ds = dataset + (size_t)cloud * n * 3;
+  int *out = idxs + (size_t)cloud * m;
+  unsigned long long *cs = slots + (size_t)cloud * 4 * G;  // [parity][2][G]
+  const int k0 = g * S, k1 = min(n, k0 + S);
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  unsigned nkey[PPT];
+  bool live[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int k = k0 + tid + p * T;
+    const bool in = k < k1;
+    const float x = in ? ds[(size_t)k * 3 + 0] : 0.f;
+    const float y = in ? ds[(size_t)k * 3 + 1] : 0.f;
+    const float z = in ? ds[(size_t)k * 3 + 2] : 0.f;
+    px[p] = x; py[p] = y; pz[p] = z;
+    td[p] = 1e10f;
+    const float mag = (x * x) + (y * y) + (z * z);
+    live[p] = in && !(mag < 1e-3f);
+    nkey[p] = ~fps_key(k, L);
+  }
+  if (g == 0 && tid == 0) out[0] = 0;
+
+  const long long kEmpty = ((long long)__float_as_int(-1.0f) << 32) | 0xFFFFFFFFll;
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = ds[(size_t)old * 3 + 0], y1 = ds[(size_t)old * 3 + 1], z1 = ds[(size_t)old * 3 + 2];
+    long long best = kEmpty;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const float d = p2r_sqdist(px[p], py[p], pz[p], x1, y1, z1);
+      const float d2 = fminf(d, td[p]);
+      if (live[p]) {
+        td[p] = d2;
+        best = i64max(best, ((long long)__float_as_int(d2) << 32) | (long long)nkey[p]);
+      }
+    }
+    best = wave_max_i64(best);
+    const int buf = j & 1;
+    if ((tid & 63) == 0) s_slot[buf][tid >> 6] = best;
+    __syncthreads();
+    if (tid < 64) {
+      long long r = s_slot[buf][0];
+#pragma unroll
+      for (int w = 1; w < W; ++w) r = i64max(r, s_slot[buf][w]);
+      unsigned long long *row = cs + (size_t)buf * 2 * G;
+      const unsigned long long tag = (unsigned)j;
+      if (tid == 0) {
+        __hip_atomic_store(row + g, ((unsigned long long)(unsigned)(r >> 32) << 32) | tag, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(row + G + g, ((unsigned long long)(unsigned)r << 32) | tag, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // lanes 0..G-1 watch the distance granules, lanes 32..32+G-1 the key granules
+      const int q = tid & 31;  // G <= 32
+      const bool watch = q < G;
+      const unsigned long long *src = row + (tid < 32 ? 0 : G) + (watch ? q : 0);
+      unsigned long long v = 0;
+      int spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = !watch || (unsigned)v == (unsigned)j;
+        if (__all(ok)) break;
+        if (++spins > (1 << 22)) break;  // never hang the device on a lost peer
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned hi = (unsigned)(v >> 32);
+      const unsigned other = __shfl_xor(hi, 32, 64);  // pair distance bits with key bits
+      long long cand = kEmpty;
+      if (watch && tid < 32) cand = ((long long)(int)hi << 32) | (long long)other;
+      cand = wave_max_i64(cand);
+      if (tid == 0) s_old[buf] = fps_unkey(~(unsigned)(cand & 0xFFFFFFFFll), L);
+    }
+    __syncthreads();
+    old = s_old[buf];
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (g == 0 && tid == 0) out[j] = old;
+  }
+}
+
+template <int PPT>
+int launch_coop(int b, int G, int S, int n, int m, int L, const float *dataset, float *temp, int *idxs,
+                hipStream_t st) {
+  const size_t slot_bytes = (size_t)b * 4 * G * sizeof(unsigned long long);
+  {
+    hipError_t e = hipMemsetAsync(temp, 0, slot_bytes, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((fps_coop_kernel<PPT>), dim3(b * G), dim3(1024), 0, st, b, G, S, n, m, L, dataset,
+                     reinterpret_cast<unsigned long long *>(temp), idxs);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
 template <int W, int PPT>
 int launch_reg(int b, int n, int m, int L, const float *dataset, int *idxs, hipStream_t st) {
   const size_t xyz_bytes = (size_t)n * 3 * sizeof(float);
@@ -199,6 +314,19 @@ extern "C" int p2r_furthest_point_sampling(int b, int n, int m, const float *dat
   if (n <= 8192) return launch_reg<16, 8>(b, n, m, L, dataset, idxs, st);
   if (n <= 16384) return launch_reg<16, 16>(b, n, m, L, dataset, idxs, st);
   if (temp == nullptr) return P2R_EINVAL;
+  // Several workgroups per cloud when the batch leaves compute units idle
+  // (the `temp` scratch, b*n floats, holds the exchange slots).
+  int G = 1;
+  while (G * 2 <= 16 && b * (G * 2) <= 256) G *= 2;  // 16 per cloud measured best (32: slower polls)
+  const int S = (n + G - 1) / G;
+  if (G >= 2 && S <= 16384 && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 &&
+      (size_t)b * 4 * G * sizeof(unsigned long long) <= (size_t)b * n * sizeof(float)) {
+    if (S <= 1024) return launch_coop<1>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    if (S <= 2048) return launch_coop<2>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    if (S <= 4096) return launch_coop<4>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    if (S <= 8192) return launch_coop<8>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    return launch_coop<16>(b, G, S, n, m, L, dataset, temp, idxs, st);
+  }
   hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, L, dataset, temp, idxs);
   P2R_LAUNCH_CHECK();
   return P2R_OK;

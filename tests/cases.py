@@ -38,6 +38,9 @@ FPS_CASES = [  # (b, n, m, kind, seed)
     (1, 2048, 256, "lattice", 13), (1, 5000, 128, "uniform", 14), (1, 9000, 64, "uniform", 15),
     (1, 16384, 32, "lattice", 16), (1, 20000, 48, "uniform", 17), (2, 33, 7, "lattice", 18),
     (1, 700, 64, "lattice", 19), (1, 3000, 64, "halflattice", 20),
+    # beyond one workgroup's register file: several workgroups per cloud
+    (8, 54272, 40, "uniform", 21), (3, 17000, 33, "lattice", 22), (16, 16500, 20, "halflattice", 23),
+    (40, 16400, 6, "uniform", 24), (2, 70000, 300, "duplicates", 25),
 ]
 
 BALL_CASES = [  # (b, n, m, radius, nsample, kind, seed)
