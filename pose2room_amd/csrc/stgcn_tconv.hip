@@ -93,7 +93,12 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       }
     }
     __syncthreads();
+#ifndef TWX_NOLOAD
     if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
+#endif
+#ifdef TWX_NOMFMA
+    continue;
+#endif
 
     int colv[TC_NT], base[TC_NT];
     bool valid[TC_NT];
@@ -183,7 +188,10 @@ constexpr int TW_F = 4;
 constexpr int TW_THREADS = 64 * TW_WAVES;
 constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves = 4 ci tiles x TW_WAVES/4 row groups)
 
-template <int TAPS>
+// VS = compile-time joint count (0: run time).  With VS fixed the reduction loop is fully unrolled and every
+// LDS read carries an immediate offset: no address arithmetic on the VALU, which on gfx950 does not overlap
+// with the partner waves' MFMAs.
+template <int TAPS, int VS>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
@@ -250,6 +258,9 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   if (tile < total_tiles) issue_loads(tile);
   for (; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();                                   // previous tile fully consumed
+#ifdef TWX_NOSTAGE
+    if (tile == (int)blockIdx.x)
+#endif
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
       const int c = wave + hh * (TW_THREADS / 64);
@@ -274,28 +285,53 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
 
     const float *drow = ds + (16 * TW_MT * mh + r) * row_d + g;  // + 16*m rows, + 4*s columns
     const float *hrow = hs + (16 * nt + r) * row_h + g;          // + p*V, + 4*s columns
-    const int steps = (TW_F * V + 3) / 4;
     // operands of step s+1 are read while the MFMAs of step s run (the rows are zero-padded past the last step)
     float a[TW_MT], b[TAPS];
 #pragma unroll
     for (int m = 0; m < TW_MT; ++m) a[m] = drow[16 * m * row_d];
+    if constexpr (VS > 0) {
+      constexpr int STEPS = (TW_F * VS + 3) / 4;
 #pragma unroll
-    for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * V];
-    for (int s = 0; s < steps; ++s) {
-      float na[TW_MT], nb[TAPS];
+      for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * VS];
 #pragma unroll
-      for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
+      for (int s = 0; s < STEPS; ++s) {
+        float na[TW_MT], nb[TAPS];
 #pragma unroll
-      for (int p = 0; p < TAPS; ++p) nb[p] = hrow[p * V + 4 * s + 4];
+        for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
 #pragma unroll
-      for (int p = 0; p < TAPS; ++p)
+        for (int p = 0; p < TAPS; ++p) nb[p] = hrow[p * VS + 4 * s + 4];
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of step s+1 ahead of the MFMAs of step s
 #pragma unroll
-        for (int m = 0; m < TW_MT; ++m)
-          acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[p], acc[p][m], 0, 0, 0);
+        for (int p = 0; p < TAPS; ++p)
 #pragma unroll
-      for (int m = 0; m < TW_MT; ++m) a[m] = na[m];
+          for (int m = 0; m < TW_MT; ++m)
+            acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[p], acc[p][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
+        for (int m = 0; m < TW_MT; ++m) a[m] = na[m];
+#pragma unroll
+        for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
+      }
+    } else {
+      const int steps = (TW_F * V + 3) / 4;
+#pragma unroll
+      for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * V];
+      for (int s = 0; s < steps; ++s) {
+        float na[TW_MT], nb[TAPS];
+#pragma unroll
+        for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
+#pragma unroll
+        for (int p = 0; p < TAPS; ++p) nb[p] = hrow[p * V + 4 * s + 4];
+#pragma unroll
+        for (int p = 0; p < TAPS; ++p)
+#pragma unroll
+          for (int m = 0; m < TW_MT; ++m)
+            acc[p][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[p], acc[p][m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < TW_MT; ++m) a[m] = na[m];
+#pragma unroll
+        for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
+      }
     }
   }
   if (dbias_partial) {
@@ -362,7 +398,7 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const floa
                    : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream);
 }
 
-template <int TAPS>
+template <int TAPS, int VS>
 static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
                            void *stream) {
@@ -375,10 +411,10 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   if (lds > 160 * 1024 || TW_F * V > 256 || (TW_F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
-    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS>, lds_ok);
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS>, lds_ok);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(tconv_dw_kernel<TAPS>, dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
+  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
                      row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
@@ -391,6 +427,10 @@ extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const 
                                            float *dw_partial, float *dbias_partial, void *stream) {
   if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1 || (taps != 1 && taps != 3)) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  return taps == 3 ? tconv_dw_launch<3>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
-                   : tconv_dw_launch<1>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
+  if (V == 53)   // the P2RNet skeleton: fully unrolled reduction loop
+    return taps == 3
+               ? tconv_dw_launch<3, 53>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
+               : tconv_dw_launch<1, 53>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
+  return taps == 3 ? tconv_dw_launch<3, 0>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
+                   : tconv_dw_launch<1, 0>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
 }
