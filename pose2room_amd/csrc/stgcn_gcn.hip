@@ -329,6 +329,12 @@ constexpr int DW_THREADS = 64 * 4 * DW_SETS;
 constexpr int DW_NW = DW_THREADS / 64;
 constexpr int DW_CS = (GC_C * DW_MAXV + DW_THREADS - 1) / DW_THREADS;   // (channel, joint) column sums owned per thread
 
+__host__ __device__ constexpr int dw_row_len(int V) {   // row stride == 2 (mod 32): conflict-free column reads
+  int r = DW_F * V;
+  while (r % 32 != 2) ++r;
+  return r;
+}
+
 struct DwSets {                   // host-balanced split of the planes over the DW_SETS groups of four waves
   int plane[DW_SETS][DW_PL];      // plane id or -1
 };
@@ -358,6 +364,7 @@ __device__ __forceinline__ void dw_plane(const int2 *__restrict__ trow, int tstr
   }
 }
 
+template <int VS>
 __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kernel(GcnParams p, DwSets sets, int n_seq,
                                                                int row_len, int ltot,
                                                                const float *__restrict__ x,
@@ -368,9 +375,11 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
                                                                float *__restrict__ colsum_partial,
                                                                int colsum_of_x) {
   extern __shared__ float lds[];
-  float *dzs = lds;                                   // [64][row_len]
-  float *xs = lds + GC_C * row_len;                   // [64][row_len]
-  int2 *tbl = reinterpret_cast<int2 *>(lds + 2 * GC_C * row_len);   // [ltot][V] (nbr, coef)
+  const int V = VS > 0 ? VS : p.V;                    // compile-time joint count: immediate LDS offsets
+  const int RL = VS > 0 ? dw_row_len(VS) : row_len;
+  float *dzs = lds;                                   // [64][RL]
+  float *xs = lds + GC_C * RL;                   // [64][RL]
+  int2 *tbl = reinterpret_cast<int2 *>(lds + 2 * GC_C * RL);   // [ltot][V] (nbr, coef)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -380,26 +389,26 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
   const int nt = wave & 3;                            // 16 ci columns owned by this wave
   const int half = wave >> 2;                         // which plane set
 
-  for (int e = tid; e < ltot * p.V; e += DW_THREADS)
+  for (int e = tid; e < ltot * V; e += DW_THREADS)
     tbl[e] = make_int2((int)nbr[e], __float_as_int(coef[e]));
 
   const int tiles_per_seq = (p.T + DW_F - 1) / DW_F;
   const int total_tiles = n_seq * tiles_per_seq;
-  const size_t row_stride = (size_t)p.T * p.V;
-  const int n_groups = (p.V + 3) / 4;
+  const size_t row_stride = (size_t)p.T * V;
+  const int n_groups = (V + 3) / 4;
 
   // longest real list (non-zero coefficient) among the four joints of each (plane, joint group): the
   // gathers of one MFMA step only need that many slots, and a group a plane does not reach is skipped
-  int *glen = reinterpret_cast<int *>(tbl + ltot * p.V);             // [K][DW_MAXV / 4]
+  int *glen = reinterpret_cast<int *>(tbl + ltot * V);             // [K][DW_MAXV / 4]
   float *cs = reinterpret_cast<float *>(glen + p.K * (DW_MAXV / 4)); // [64][V] running column sums of dZ
-  for (int e = tid; e < GC_C * p.V; e += DW_THREADS) cs[e] = 0.f;
+  for (int e = tid; e < GC_C * V; e += DW_THREADS) cs[e] = 0.f;
   __syncthreads();
   for (int e = tid; e < p.K * n_groups; e += DW_THREADS) {
     const int k = e / n_groups, wg = e - k * n_groups;
     int m = 0;
     for (int j = 0; j < p.Lk[k]; ++j)
-      for (int w = 4 * wg; w < min(4 * wg + 4, p.V); ++w)
-        if (__int_as_float(tbl[(p.Lofs[k] + j) * p.V + w].y) != 0.f) m = j + 1;
+      for (int w = 4 * wg; w < min(4 * wg + 4, V); ++w)
+        if (__int_as_float(tbl[(p.Lofs[k] + j) * V + w].y) != 0.f) m = j + 1;
     glen[k * (DW_MAXV / 4) + wg] = m;
   }
 
@@ -411,15 +420,15 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
     for (int m = 0; m < 4; ++m) acc[kk][m] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int k = sets.plane[half][kk];
     pl_k[kk] = k;
-    pl_row[kk] = k >= 0 ? p.Lofs[k] * p.V : 0;
+    pl_row[kk] = k >= 0 ? p.Lofs[k] * V : 0;
   }
 
   for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * DW_F;
-    const int ncols = min(DW_F, p.T - t0) * p.V;
-    const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
-    const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * p.V;
+    const int ncols = min(DW_F, p.T - t0) * V;
+    const float *xg = x + (size_t)seq * GC_C * row_stride + (size_t)t0 * V;
+    const float *dg = dz + (size_t)seq * GC_C * row_stride + (size_t)t0 * V;
     // stage both tiles: all loads of two rows are issued before the first LDS write so the HBM latency is paid
     // once per row pair, not once per 64-column chunk; the first row pair is requested BEFORE the barrier that
     // waits for the other waves to finish the previous tile, so its latency overlaps that wait
@@ -444,9 +453,9 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          if (q < row_len && (c + DW_NW * h) < GC_C) {
-            xs[(c + DW_NW * h) * row_len + q] = vx[h][i];
-            dzs[(c + DW_NW * h) * row_len + q] = vd[h][i];
+          if (q < RL && (c + DW_NW * h) < GC_C) {
+            xs[(c + DW_NW * h) * RL + q] = vx[h][i];
+            dzs[(c + DW_NW * h) * RL + q] = vd[h][i];
           }
         }
     }
@@ -470,9 +479,9 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
-          if (q < row_len && (c + DW_NW * h) < GC_C) {
-            xs[(c + DW_NW * h) * row_len + q] = vx[h][i];
-            dzs[(c + DW_NW * h) * row_len + q] = vd[h][i];
+          if (q < RL && (c + DW_NW * h) < GC_C) {
+            xs[(c + DW_NW * h) * RL + q] = vx[h][i];
+            dzs[(c + DW_NW * h) * RL + q] = vd[h][i];
           }
         }
     }
@@ -482,29 +491,29 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
 #pragma unroll 1
       for (int n = 0; n < DW_CS; ++n) {
         const int idx = tid + DW_THREADS * n;
-        if (idx < GC_C * p.V) {
-          const int c = idx / p.V, w = idx - c * p.V;
-          const float *dp = (colsum_of_x ? xs : dzs) + c * row_len + w;
+        if (idx < GC_C * V) {
+          const int c = idx / V, w = idx - c * V;
+          const float *dp = (colsum_of_x ? xs : dzs) + c * RL + w;
           float sum = 0.f;
 #pragma unroll
-          for (int f = 0; f < DW_F; ++f) sum += dp[f * p.V];      // frames past the sequence end are zero-filled
+          for (int f = 0; f < DW_F; ++f) sum += dp[f * V];      // frames past the sequence end are zero-filled
           cs[idx] += sum;                                         // element owned by this thread: no atomics
         }
       }
     }
 
-    const float *xrow = xs + (16 * nt + r) * row_len;   // this lane's ci row
-    const float *drow = dzs + r * row_len;               // + 16*m rows
+    const float *xrow = xs + (16 * nt + r) * RL;   // this lane's ci row
+    const float *drow = dzs + r * RL;               // + 16*m rows
     for (int wg = 0; wg < n_groups; ++wg) {
       const int w = 4 * wg + g;
       const int *gl_w = glen + wg;
-      const bool live = w < p.V;
+      const bool live = w < V;
       const int wc = live ? w : 0;
       float a[4][DW_F];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int f = 0; f < DW_F; ++f) a[m][f] = live ? drow[16 * m * row_len + f * p.V + wc] : 0.f;
+        for (int f = 0; f < DW_F; ++f) a[m][f] = live ? drow[16 * m * RL + f * V + wc] : 0.f;
 #pragma unroll
       for (int kk = 0; kk < DW_PL; ++kk) {
         if (pl_k[kk] < 0) continue;                      // uniform
@@ -516,21 +525,21 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
         for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
         // lists longer than six go in two passes: bounds the live gather registers (no scratch)
 #if DW_SETS == 2
-        if (Lr <= 1) dw_plane<1>(trow, p.V, xrow, p.V, live, Lr, b);
-        else if (Lr <= 3) dw_plane<3>(trow, p.V, xrow, p.V, live, Lr, b);
-        else if (Lr <= 6) dw_plane<6>(trow, p.V, xrow, p.V, live, Lr, b);
+        if (Lr <= 1) dw_plane<1>(trow, V, xrow, V, live, Lr, b);
+        else if (Lr <= 3) dw_plane<3>(trow, V, xrow, V, live, Lr, b);
+        else if (Lr <= 6) dw_plane<6>(trow, V, xrow, V, live, Lr, b);
         else {
-          dw_plane<6>(trow, p.V, xrow, p.V, live, 6, b);
-          if (Lr <= 9) dw_plane<3>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
-          else dw_plane<6>(trow + 6 * p.V, p.V, xrow, p.V, live, Lr - 6, b);
+          dw_plane<6>(trow, V, xrow, V, live, 6, b);
+          if (Lr <= 9) dw_plane<3>(trow + 6 * V, V, xrow, V, live, Lr - 6, b);
+          else dw_plane<6>(trow + 6 * V, V, xrow, V, live, Lr - 6, b);
         }
 #else
         // tighter register budget: passes of at most three list entries
 #ifndef DWX_NOGATHER
         for (int j0 = 0; j0 < Lr; j0 += 3) {
           const int rem = Lr - j0;
-          if (rem <= 1) dw_plane<1>(trow + j0 * p.V, p.V, xrow, p.V, live, rem, b);
-          else dw_plane<3>(trow + j0 * p.V, p.V, xrow, p.V, live, rem < 3 ? rem : 3, b);
+          if (rem <= 1) dw_plane<1>(trow + j0 * V, V, xrow, V, live, rem, b);
+          else dw_plane<3>(trow + j0 * V, V, xrow, V, live, rem < 3 ? rem : 3, b);
         }
 #else
         b[0] = b[1] = b[2] = b[3] = a[0][0];
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
 #pragma unroll
     for (int n = 0; n < DW_CS; ++n) {
       const int idx = tid + DW_THREADS * n;
-      if (idx < GC_C * p.V) colsum_partial[(size_t)blockIdx.x * GC_C * p.V + idx] = cs[idx];
+      if (idx < GC_C * V) colsum_partial[(size_t)blockIdx.x * GC_C * V + idx] = cs[idx];
     }
   }
   // partial[block][k][c][ci]: D[row = 4*g + q][col = r] -> c = 16*m + row, ci = 16*nt + r
@@ -831,18 +840,23 @@ extern "C" int p2r_stgcn_gcn_weight_grad(int N, int T, int V, int K, const int *
     sets.plane[h][cnt[h]++] = order[i];
     load[h] += p.Lk[order[i]] + 4;   // gathers + the 16 MFMAs a plane costs per frame group
   }
-  int row_len = DW_F * V;
-  while (row_len % 32 != 2) ++row_len;   // row stride == 2 (mod 32): conflict-free column reads
+  const int row_len = dw_row_len(V);
   const size_t lds = 2 * (size_t)GC_C * row_len * sizeof(float) + (size_t)ltot * V * sizeof(int2) +
                      (size_t)K * (DW_MAXV / 4) * sizeof(int) + (size_t)GC_C * V * sizeof(float);
   if (lds > 160 * 1024 || row_len > 256) return P2R_EINVAL;
-  static unsigned char lds_ok[P2R_MAX_DEVICES];
-  {
-    hipError_t e = p2r_allow_big_lds(gcn_dw_kernel, lds_ok);
+  if (V == 53) {   // the P2RNet skeleton
+    static unsigned char lds_ok[P2R_MAX_DEVICES];
+    hipError_t e = p2r_allow_big_lds(gcn_dw_kernel<53>, lds_ok);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gcn_dw_kernel<53>, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
+                       row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial, colsum_of_x);
+  } else {
+    static unsigned char lds_ok[P2R_MAX_DEVICES];
+    hipError_t e = p2r_allow_big_lds(gcn_dw_kernel<0>, lds_ok);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gcn_dw_kernel<0>, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
+                       row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial, colsum_of_x);
   }
-  hipLaunchKernelGGL(gcn_dw_kernel, dim3(n_blocks), dim3(DW_THREADS), lds, p2r_stream(stream), p, sets, N,
-                     row_len, ltot, x, dz, nbr, coef, dw_partial, colsum_partial, colsum_of_x);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
