@@ -766,8 +766,15 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         for (int s = 0; s < 16; ++s)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
+#ifndef DCX_NOMFMA
             h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bz[i][s], h[m], 0, 0, 0);
+#else
+            h[m][s & 3] += a[m][s] * bz[i][s & 1];
+#endif
         // h[m][q] = H_k[ci = 16m + 4g + q][col_i]
+#ifdef DCX_NOREDUCE
+        if (h[0][0] + h[1][1] + h[2][2] + h[3][3] == 123.456f) dcs[tid] = 1.f;
+#else
         if (valid[i]) {
           const int2 *trow = tbl + lofs * p.V + wj[i];
           float *drow = dcs + lofs * p.V + wj[i];
@@ -785,6 +792,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
             default: dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
           }
         }
+#endif
       }
     }
   }
