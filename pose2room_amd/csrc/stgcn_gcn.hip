@@ -676,10 +676,53 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
   // Columns of a tile are taken JOINT-major (column c of the MFMA n-tiles = frame c % F of joint c / F, F = frames of
   // a full tile): the 16 columns of an n-tile then span 3-4 joints instead of 16, and 33 % of the (plane, n-tile)
   // units of the row lists are empty instead of 19 % (177 vs 213 units of 264 per tile).
+  //
+  // The n-tiles are dealt to the waves by cost (number of planes that reach the tile), not in order: with the
+  // P2RNet graph the first 8 of the 24 tiles carry 8-11 planes each and the rest 6, so waves 0-2 would own
+  // 27-33 (plane, n-tile) units against 18 for the others; dealt greedily (largest first, to the least loaded
+  // wave) every wave owns 20-23.
+  constexpr int DC_NTT = (DC_THREADS / 64) * GC_NT16;
+  int *s_cost = reinterpret_cast<int *>(dcs + ltot * p.V), *s_tile = s_cost + DC_NTT;   // [DC_NTT] each
+  for (int t = wave; t < DC_NTT; t += DC_THREADS / 64) {
+    const int col = t * 16 + r;
+    const bool in = col < p.F * p.V;
+    const int w = in ? col / p.F : 0;
+    int c = 0;
+    for (int k = 0; k < p.K; ++k) {
+      bool any = false;
+      for (int j = 0; j < p.Lk[k]; ++j) {
+        const int mark = tbl[(p.Lofs[k] + j) * p.V + w].y;
+        if (in && (mark == 1 || (mark == 2 && j == 0))) any = true;
+      }
+      if (__ballot(any) != 0ull) ++c;
+    }
+    if (lane == 0) s_cost[t] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int load[DC_THREADS / 64], cnt[DC_THREADS / 64];
+    for (int w = 0; w < DC_THREADS / 64; ++w) load[w] = cnt[w] = 0;
+    for (int n = 0; n < DC_NTT; ++n) {
+      int best = -1;
+      for (int t = 0; t < DC_NTT; ++t)
+        if (s_cost[t] >= 0 && (best < 0 || s_cost[t] > s_cost[best])) best = t;
+      int to = -1;
+      for (int w = 0; w < DC_THREADS / 64; ++w)
+        if (cnt[w] < GC_NT16 && (to < 0 || load[w] < load[to])) to = w;
+      s_tile[to * GC_NT16 + cnt[to]++] = best;
+      load[to] += s_cost[best] + 1;
+      s_cost[best] = -1;
+    }
+  }
+  __syncthreads();
+  int ntile[GC_NT16];
+#pragma unroll
+  for (int i = 0; i < GC_NT16; ++i) ntile[i] = __builtin_amdgcn_readfirstlane(s_tile[wave * GC_NT16 + i]);
+
   int tlen[GC_NT16];                       // plane k's value lives in lane k of the wave
 #pragma unroll
   for (int i = 0; i < GC_NT16; ++i) {
-    const int col = (wave * GC_NT16 + i) * 16 + r;
+    const int col = ntile[i] * 16 + r;
     const bool in = col < p.F * p.V;
     const int w = in ? col / p.F : 0;
     int mine = 0;
@@ -714,16 +757,23 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
     float bz[GC_NT16][16];               // dZ[c = 16g + s][col]: B operands, reused by every plane
 #pragma unroll
     for (int i = 0; i < GC_NT16; ++i) {
-      const int col = (wave * GC_NT16 + i) * 16 + r;
+      const int col = ntile[i] * 16 + r;
       const int jn = col / p.F, f = col - jn * p.F;          // joint-major column -> (joint, frame)
       valid[i] = jn < p.V && f * p.V < ncols;
       wj[i] = valid[i] ? jn : 0;
       fbase[i] = valid[i] ? f * p.V : 0;
 #pragma unroll
       for (int s = 0; s < 16; ++s)
+#ifdef DCX_NOBZ
+        bz[i][s] = (float)(s + i);
+#else
         bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + fbase[i] + wj[i]] : 0.f;
+#endif
     }
     __syncthreads();
+#ifdef DCX_NOSTAGE
+    if (tile == (int)blockIdx.x)
+#endif
 #pragma unroll 1
     for (int rg = wave; rg < GC_C / 4; rg += DC_THREADS / 64) {       // row group = 4 consecutive rows
       float v[4][GC_NP / 64];
@@ -750,7 +800,11 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         const float4 *wp = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#ifdef DCX_NOW
+          const float4 u = make_float4((float)k, (float)m, (float)q, 1.f);
+#else
           const float4 u = wp[q];
+#endif
           a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
         }
       }
@@ -879,7 +933,8 @@ extern "C" int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk
   if (ltot < 0) return ltot;
   if (N < 0 || n_blocks < 1) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
-  const size_t lds = (size_t)16 * DC_ROW4 * sizeof(float4) + (size_t)ltot * V * (sizeof(int2) + sizeof(float));
+  const size_t lds = (size_t)16 * DC_ROW4 * sizeof(float4) + (size_t)ltot * V * (sizeof(int2) + sizeof(float)) +
+                     2 * (DC_THREADS / 64) * GC_NT16 * sizeof(int);
   if (lds > 160 * 1024) return P2R_EINVAL;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
