@@ -243,12 +243,20 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int G, int S, int
       const unsigned long long *src = row + (tid < 32 ? 0 : G) + (watch ? q : 0);
       unsigned long long v = 0;
       int spins = 0;
+      bool lost = false;
       for (;;) {
         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool ok = !watch || (unsigned)v == (unsigned)j;
         if (__all(ok)) break;
-        if (++spins > (1 << 22)) break;  // never hang the device on a lost peer
+        if (++spins > (1 << 22)) { lost = true; break; }   // never hang the device on a peer that is not resident
         __builtin_amdgcn_s_sleep(1);
+      }
+      if (lost) {   // loud, not silent: the remaining picks become -1 (out of range for every consumer)
+        if (tid == 0) s_old[buf] = -1;
+        __syncthreads();
+        if (g == 0)
+          for (int jj = j + tid; jj < m; jj += 64) out[jj] = -1;
+        return;
       }
       const unsigned hi = (unsigned)(v >> 32);
       const unsigned other = __shfl_xor(hi, 32, 64);  // pair distance bits with key bits
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int G, int S, int
     __syncthreads();
     old = s_old[buf];
     old = __builtin_amdgcn_readfirstlane(old);
+    if (old < 0) return;                                   // the first wave gave up (see above)
     if (g == 0 && tid == 0) out[j] = old;
   }
 }
@@ -316,8 +325,17 @@ extern "C" int p2r_furthest_point_sampling(int b, int n, int m, const float *dat
   if (temp == nullptr) return P2R_EINVAL;
   // Several workgroups per cloud when the batch leaves compute units idle
   // (the `temp` scratch, b*n floats, holds the exchange slots).
+  // every workgroup of the launch must be resident at once (they wait for each other): one per compute unit
+  static int n_cu[P2R_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= P2R_MAX_DEVICES) return P2R_EINVAL;
+  if (n_cu[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 1;
+    n_cu[dev] = v;
+  }
   int G = 1;
-  while (G * 2 <= 16 && b * (G * 2) <= 256) G *= 2;  // 16 per cloud measured best (32: slower polls)
+  while (G * 2 <= 16 && b * (G * 2) <= n_cu[dev]) G *= 2;  // 16 per cloud measured best (32: slower polls)
   const int S = (n + G - 1) / G;
   if (G >= 2 && S <= 16384 && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 &&
       (size_t)b * 4 * G * sizeof(unsigned long long) <= (size_t)b * n * sizeof(float)) {
