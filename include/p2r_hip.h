@@ -279,10 +279,11 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
  * M = elements per channel.  out [4][C] = mean, invstd = 1/sqrt(var + eps), scale = gamma*invstd,
  * shift = beta - mean*scale (biased variance, fp64 combination).  momentum >= 0 also updates
  * running_mean / running_var in place as nn.BatchNorm does (unbiased variance); momentum < 0 leaves
- * them untouched (they may be NULL then). */
+ * them untouched (they may be NULL then).  num_batches_tracked (device int64 scalar, may be NULL) is
+ * incremented by one, as nn.BatchNorm's forward does in training mode. */
 int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma,
                     const float *beta, double eps, double momentum, float *running_mean,
-                    float *running_var, float *out, void *stream);
+                    float *running_var, long long *num_batches_tracked, float *out, void *stream);
 
 /* backward counterpart: partial [P][C][2] = (sum g, sum g*xhat) rows -> out [4][C] =
  * sum g (= dbeta), sum g*xhat (= dgamma), (sum g)/M, (sum g*xhat)/M. */

@@ -320,8 +320,10 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(int P, int C, 
                                                                   const float *__restrict__ beta, double eps,
                                                                   double momentum, float *__restrict__ running_mean,
                                                                   float *__restrict__ running_var,
+                                                                  long long *__restrict__ num_batches_tracked,
                                                                   float *__restrict__ out) {
   const int c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
   double s = 0.0, q = 0.0;
   for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
     const float2 v = partial[(size_t)p * C + c];
@@ -368,12 +370,12 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(int P, int
 }  // namespace
 
 extern "C" int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma, const float *beta,
-                               double eps, double momentum, float *running_mean, float *running_var, float *out,
-                               void *stream) {
+                               double eps, double momentum, float *running_mean, float *running_var,
+                               long long *num_batches_tracked, float *out, void *stream) {
   if (P <= 0 || C <= 0 || M <= 0.0) return P2R_EINVAL;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, p2r_stream(stream), P, C,
                      reinterpret_cast<const float2 *>(partial), M, gamma, beta, eps, momentum, running_mean,
-                     running_var, out);
+                     running_var, num_batches_tracked, out);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

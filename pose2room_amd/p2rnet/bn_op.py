@@ -49,10 +49,9 @@ def finalize(part, M, bn):
     with torch.cuda.device(part.device):
         _lib.check(_lib.lib().p2r_bn_finalize(P, C, _lib.ptr(part), ctypes.c_double(float(M)), _lib.ptr(bn.weight),
                                               _lib.ptr(bn.bias), ctypes.c_double(float(bn.eps)), ctypes.c_double(mom),
-                                              _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(fin),
+                                              _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                                              _lib.ptr(bn.num_batches_tracked), _lib.ptr(fin),
                                               _lib.current_stream(part.device)), "bn_finalize")
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
     return fin
 
 

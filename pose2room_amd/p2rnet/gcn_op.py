@@ -120,7 +120,6 @@ class _GraphConv(Function):
         dz = dz.contiguous()
         N, C, T, V = x.shape
         K = tables.K
-        Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
         dx = dW = dcoef_r = dbias = None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
@@ -129,6 +128,7 @@ class _GraphConv(Function):
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None)
                 dres = None
             else:
+                Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
                 dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
         st = _lib.current_stream(dev)

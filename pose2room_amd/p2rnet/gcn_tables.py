@@ -42,63 +42,12 @@ def coefficients(Aeff, gidx):
     """Aeff (K,V,V) -> coef [sum L_k, V] with zeros at padded slots (differentiable)."""
     flat = Aeff.reshape(-1)
     safe = gidx.clamp(min=0)
-    return torch.where(gidx >= 0, flat[safe], torch.zeros((), dtype=Aeff.dtype, device=Aeff.device))
+    # index_select (backward: one index_add_) instead of advanced indexing (backward: a sort-based index_put_)
+    vals = flat.index_select(0, safe.reshape(-1)).view_as(gidx)
+    return torch.where(gidx >= 0, vals, torch.zeros((), dtype=Aeff.dtype, device=Aeff.device))
 
 
 STREAM_UMAX, STREAM_REC, STREAM_HDR = 80, 12, 16     # csrc/stgcn_gcn2.hip: G2_UMAX, G2_REC, G2_HDR
-
-
-def deal_joints(cost, n_waves, slots):
-    """Joints -> (wave, slot) owners with equal MFMA work.  cost[w] = number of non-empty (plane, w) units.
-    The matrix pipe is per SIMD and waves i, i + 4, i + 8, .. of a workgroup share one: the SIMDs are balanced
-    first (that is what bounds the kernel), then the waves of each SIMD."""
-    V = len(cost)
-
-    def deal(items, bins, cap):
-        """longest-processing-time-first into `bins` bins of at most `cap` items, then pairwise moves / swaps off
-        the fullest bin (the item cap defeats plain LPT)"""
-        own, ld = [[] for _ in range(bins)], [0] * bins
-        for w in sorted(items, key=lambda j: (-cost[j], j)):
-            i = min((c for c in range(bins) if len(own[c]) < cap), key=lambda c: (ld[c], c))
-            own[i].append(w)
-            ld[i] += int(cost[w])
-        improved = True
-        while improved:
-            improved = False
-            hi = max(range(bins), key=lambda c: ld[c])
-            for lo in sorted(range(bins), key=lambda c: ld[c]):
-                gap = ld[hi] - ld[lo]
-                if lo == hi or gap <= 1:
-                    continue
-                best = None
-                for a in own[hi]:
-                    if len(own[lo]) < cap and 0 < cost[a] < gap:
-                        best = (a, None)
-                        break
-                    for b_ in own[lo]:
-                        if 0 < cost[a] - cost[b_] < gap:
-                            best = (a, b_)
-                            break
-                    if best:
-                        break
-                if best:
-                    a, b_ = best
-                    own[hi].remove(a); own[lo].append(a)
-                    ld[hi] -= int(cost[a]); ld[lo] += int(cost[a])
-                    if b_ is not None:
-                        own[lo].remove(b_); own[hi].append(b_)
-                        ld[lo] -= int(cost[b_]); ld[hi] += int(cost[b_])
-                    improved = True
-                    break
-        return [sorted(o) for o in own]
-
-    assert n_waves % 4 == 0 and n_waves * slots >= V
-    per_simd = n_waves // 4
-    owner = [None] * n_waves
-    for sidx, group in enumerate(deal(range(V), 4, per_simd * slots)):
-        for j, part in enumerate(deal(group, per_simd, slots)):
-            owner[sidx + 4 * j] = part
-    return owner
 
 
 def deal_runs(cost, n_waves, slots):
