@@ -159,6 +159,18 @@ _NAMES32 = ('vote_loss', 'objectness_loss', 'center_loss', 'size_loss', 'sem_cls
             'obj_acc')
 
 
+_TERM_WEIGHTS = {}
+
+
+def _term_weights(device):
+    """[6] f64: weights of (vote, objectness, center, size, heading, sem_cls) in `total`
+    (models/loss.py:167 of the reference: 10, 5, 10, 10, 10, 1)."""
+    key = str(device)
+    if key not in _TERM_WEIGHTS:
+        _TERM_WEIGHTS[key] = torch.tensor([10.0, 5.0, 10.0, 10.0, 10.0, 1.0], dtype=torch.float64, device=device)
+    return _TERM_WEIGHTS[key]
+
+
 class _DetectionLoss(Function):
     """Inputs with gradient: vote_xyz, objectness_scores, center, size, heading (f64), sem_cls_scores.
     Outputs: the ten loss-dict entries in the reference's dtypes (`heading_loss`, `total` f64, the rest f32)."""
@@ -198,6 +210,7 @@ class _DetectionLoss(Function):
                 _lib.ptr(out32), _lib.ptr(out64), _lib.ptr(g_vote), _lib.ptr(g_obj), _lib.ptr(g_c1), _lib.ptr(g_c2),
                 _lib.ptr(g_size), _lib.ptr(g_head), _lib.ptr(g_sem), _lib.current_stream(dev)), "det_loss_forward")
         ctx.save_for_backward(out32, g_vote, g_obj, g_c1, g_c2, g_size, g_head, g_sem)
+        ctx.set_materialize_grads(False)      # unused loss terms arrive as None, not as zero tensors
         ctx.dims = (B, S, K, NC)
         outs = tuple(out32[i] for i in range(8)) + (out64[0], out64[1])
         ctx.mark_non_differentiable(outs[5], outs[6], outs[7])
@@ -208,10 +221,14 @@ class _DetectionLoss(Function):
         out32, g_vote, g_obj, g_c1, g_c2, g_size, g_head, g_sem = ctx.saved_tensors
         B, S, K, NC = ctx.dims
         dev = out32.device
-        zero = torch.zeros((), dtype=torch.float64, device=dev)
-        dt = d_total.double() if d_total is not None else zero
         terms = [(d_vote, 10.0), (d_obj, 5.0), (d_center, 10.0), (d_size, 10.0), (d_head, 10.0), (d_sem, 1.0)]
-        coef = torch.stack([dt * w + (g.double() if g is not None else zero) for g, w in terms]).contiguous()
+        if d_total is not None and all(g is None for g, _ in terms):
+            # the training step: only `total` is back-propagated -> one launch for the six term coefficients
+            coef = (d_total.double() * _term_weights(dev)).contiguous()
+        else:
+            zero = torch.zeros((), dtype=torch.float64, device=dev)
+            dt = d_total.double() if d_total is not None else zero
+            coef = torch.stack([dt * w + (g.double() if g is not None else zero) for g, w in terms]).contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         o_vote = torch.empty((B, S, 3), **f32)
         o_obj, o_center, o_size = (torch.empty((B, K, d), **f32) for d in (2, 3, 3))
