@@ -316,10 +316,14 @@ int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, c
  * frames of one joint, channel phases double-buffered in LDS by LDS-DMA, persistent workgroups, input transform
  * applied on the B operand.  Wp [3][4][4][64][4]: Wp[p][ph][m][16 g + r][s] = W[p][16 m + r][16 ph + 4 s + g].
  * scale / shift both NULL = no input transform (the data-gradient launch, with flipped / transposed taps).
- * stats_partial [*n_partials][64][2] (optional); out == NULL queries *n_partials. */
+ * stats_partial [*n_partials][64][2] (optional); out == NULL queries *n_partials.
+ * bwd_z / bwd_fin (both or neither; data-gradient launch only, stats_partial required): the statistics epilogue
+ * then emits the reduction pass of the BatchNorm + ReLU backward of the layer in front (what p2r_bn_bwd_reduce
+ * with relu = 2 computes from `out`): per channel (sum g', sum g' * zhat), g' = out where scale*z + shift > 0,
+ * zhat = (z - mean) * invstd, z = bwd_z (N,64,T,53), bwd_fin [4][64] = (mean, invstd, scale, shift). */
 int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
                              const float *Wp, const float *bias, float *out, float *stats_partial,
-                             int *n_partials, void *stream);
+                             int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
 
 /* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
 

@@ -56,11 +56,15 @@ __device__ __forceinline__ void t2_dma4(const float *src, float *lds_dst) {
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
-template <int VT, bool XFORM>
+// BWD (data-gradient instance only): the statistics epilogue emits the two sums of the BatchNorm + ReLU backward
+// of the layer in front instead -- per channel sum g' and sum g' * zhat with g' = out where relu'(scale*z+shift),
+// zhat = (z - mean) * invstd, z = bwd_z (the saved activation), constants from bwd_fin [4][64] = (mean, invstd,
+// scale, shift).  The rows leave through LDS anyway; the extra traffic is one read of z.
+template <int VT, bool XFORM, bool BWD>
 __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
     T2Params p, const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
-    float *__restrict__ stats_partial) {
+    float *__restrict__ stats_partial, const float *__restrict__ bwd_z, const float *__restrict__ bwd_fin) {
   constexpr int V = VT, NW = T2_NW, SLOTS = T2_SLOTS;
   constexpr int RS = T2_F * V;                        // main row stride (floats): 848 == 16 (mod 32)
   constexpr int MAIN = T2_CP * RS;                    // floats of the 16-frame part of a slice
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
   float *rowstat = lds + 2 * BUF;                     // [NW][64][2]
   float *aff = rowstat + NW * 128;                    // [64][2] (scale, shift) of the input transform
   float *bias_l = aff + 128;                          // [64]
+  float *bstat = bias_l + 64;                         // [64][2] (mean, invstd) of the BWD epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -79,9 +84,11 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 
   for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
   if (tid < 64) {
-    aff[2 * tid] = XFORM ? scale[tid] : 1.f;
-    aff[2 * tid + 1] = XFORM ? shift[tid] : 0.f;
+    aff[2 * tid] = XFORM ? scale[tid] : (BWD ? bwd_fin[128 + tid] : 1.f);
+    aff[2 * tid + 1] = XFORM ? shift[tid] : (BWD ? bwd_fin[192 + tid] : 0.f);
     bias_l[tid] = bias ? bias[tid] : 0.f;
+    bstat[2 * tid] = BWD ? bwd_fin[tid] : 0.f;
+    bstat[2 * tid + 1] = BWD ? bwd_fin[64 + tid] : 1.f;
   }
   __syncthreads();
 
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
     const int frames = min(T2_F, p.T - t0);
     const float *xg = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
     float *og = out + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
+    const float *zg = BWD ? bwd_z + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * T2_F : 0;
@@ -264,7 +272,35 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 
     // ---- epilogue: statistics of the tile, then the tile itself through LDS as whole rows ------------------------
     float *rs = rowstat + wave * 128;
-    if (stats_partial) {
+    if (BWD) {
+      if (!(p.vec && frames == T2_F)) {   // ragged tile: from the accumulators, z read where the lane's values go
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = 16 * m + 4 * g + q;
+            const float sc = aff[2 * c], sh = aff[2 * c + 1], mu = bstat[2 * c], is = bstat[2 * c + 1];
+            const float *zrow = zg + (size_t)c * row_stride + r * V + j0;
+            float s1 = 0.f, s2 = 0.f;
+            if (r < frames) {
+#pragma unroll
+              for (int i = 0; i < SLOTS; ++i)
+                if (i < nslots) {
+                  const float zz = zrow[i];
+                  const float gm = fmaf(zz, sc, sh) > 0.f ? acc[i][m][q] : 0.f;
+                  s1 += gm;
+                  s2 = fmaf(gm, (zz - mu) * is, s2);
+                }
+            }
+            s1 = p2r_row16_sum(s1);
+            s2 = p2r_row16_sum(s2);
+            if (r == 0) {
+              rs[2 * c] += s1;
+              rs[2 * c + 1] += s2;
+            }
+          }
+      }
+    } else if (stats_partial) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -300,16 +336,61 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
           }
+        constexpr int R4 = RS / 4;                          // float4 per row (212)
+        constexpr int RIT = (R4 + 63) / 64;                 // 4
+        float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
+        if (BWD) {   // the saved activation of this wave's two rows: in flight across the staging barrier
+          const float4 *z4 = reinterpret_cast<const float4 *>(zg + (size_t)(16 * m + 2 * wave) * row_stride);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              zv[rr][it] = c4 < R4 ? z4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *orow = reinterpret_cast<float4 *>(og + (size_t)16 * m * row_stride);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
+        if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
 #pragma unroll
-        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
-          const int e = it * NW * 64 + tid;
-          if (e < NV4) {
-            const int row = e / (RS / 4), c4 = e - row * (RS / 4);
-            orow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, c = 16 * m + row;
+            const float sc = aff[2 * c], sh = aff[2 * c + 1], mu = bstat[2 * c], is = bstat[2 * c + 1];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              if (c4 < R4) {
+                const float4 v = srow[row * R4 + c4];
+                orow[(size_t)row * (row_stride / 4) + c4] = v;
+                const float4 zz = zv[rr][it];
+                const float g0 = fmaf(zz.x, sc, sh) > 0.f ? v.x : 0.f, g1 = fmaf(zz.y, sc, sh) > 0.f ? v.y : 0.f;
+                const float g2 = fmaf(zz.z, sc, sh) > 0.f ? v.z : 0.f, g3 = fmaf(zz.w, sc, sh) > 0.f ? v.w : 0.f;
+                s1 += (g0 + g1) + (g2 + g3);
+                s2 = fmaf(g0, (zz.x - mu) * is, s2); s2 = fmaf(g1, (zz.y - mu) * is, s2);
+                s2 = fmaf(g2, (zz.z - mu) * is, s2); s2 = fmaf(g3, (zz.w - mu) * is, s2);
+              }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              s1 += __shfl_xor(s1, off, 64);
+              s2 += __shfl_xor(s2, off, 64);
+            }
+            if (lane == 0) {
+              rs[2 * c] += s1;
+              rs[2 * c + 1] += s2;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+            const int e = it * NW * 64 + tid;
+            if (e < NV4) {
+              const int row = e / (RS / 4), c4 = e - row * (RS / 4);
+              orow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -351,8 +432,9 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 // Call with out == NULL to query *n_partials.
 extern "C" int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
                                         const float *Wp, const float *bias, float *out, float *stats_partial,
-                                        int *n_partials, void *stream) {
+                                        int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream) {
   if (N < 0 || T <= 0 || V != 53 || (scale == nullptr) != (shift == nullptr)) return P2R_EINVAL;
+  if ((bwd_z == nullptr) != (bwd_fin == nullptr) || (bwd_z && (scale || !stats_partial))) return P2R_EINVAL;
   if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
   T2Params p;
@@ -366,22 +448,29 @@ extern "C" int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, con
   if (n_partials) *n_partials = blocks;
   if (!out) return P2R_OK;
   const size_t lds = (size_t)2 * (T2_CP * T2_F * V + T2_CP * 2 * V) * sizeof(float) + (size_t)T2_NW * 128 * sizeof(float) +
-                     (size_t)(128 + 64) * sizeof(float);
+                     (size_t)(128 + 64 + 128) * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
-  if (scale) {
-    auto kern = tconv2_kernel<53, true>;
+  if (bwd_z) {
+    auto kern = tconv2_kernel<53, false, true>;
     static unsigned char lds_ok[P2R_MAX_DEVICES];
     hipError_t e = p2r_allow_big_lds(kern, lds_ok);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                       stats_partial);
+                       stats_partial, bwd_z, bwd_fin);
+  } else if (scale) {
+    auto kern = tconv2_kernel<53, true, false>;
+    static unsigned char lds_ok[P2R_MAX_DEVICES];
+    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
+                       stats_partial, nullptr, nullptr);
   } else {
-    auto kern = tconv2_kernel<53, false>;
+    auto kern = tconv2_kernel<53, false, false>;
     static unsigned char lds_ok[P2R_MAX_DEVICES];
     hipError_t e = p2r_allow_big_lds(kern, lds_ok);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                       stats_partial);
+                       stats_partial, nullptr, nullptr);
   }
   P2R_LAUNCH_CHECK();
   return P2R_OK;

@@ -28,21 +28,30 @@ def _permute_taps(W3):
     return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()
 
 
-def _tconv(x, scale, shift, W3, bias, want_stats=False):
+def _tconv2_able(W3, V):
+    return W3.shape[0] == 3 and V == 53
+
+
+def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None):
+    """bwd = (z, fin): data-gradient launch whose statistics epilogue is the reduction pass of the BatchNorm + ReLU
+    backward in front (second-generation kernel only; implies want_stats)."""
     N, C, T, V = x.shape
     out = torch.empty_like(x)
     lib = _lib.lib()
     part = None
-    if W3.shape[0] == 3 and V == 53:          # second-generation kernel
+    if _tconv2_able(W3, V):          # second-generation kernel
         Wp = _permute_taps(W3)
+        bz, bfin = (bwd[0], bwd[1].contiguous()) if bwd is not None else (None, None)
         with torch.cuda.device(x.device):
             st = _lib.current_stream(x.device)
             if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
                 part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
             _lib.check(lib.p2r_stgcn_tconv2_forward(N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
-                                                    _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None, st),
+                                                    _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None,
+                                                    _lib.ptr(bz), _lib.ptr(bfin), st),
                        "stgcn_tconv2_forward")
         return (out, part) if want_stats else out
+    assert bwd is None
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
         if want_stats:      # one (sum, sum of squares) partial per persistent workgroup: ask how many
@@ -86,26 +95,29 @@ class _BNReLUTConv(Function):
         st = _lib.current_stream(dev)
         # dh[ci, t] = sum_p W[p][c][ci] du[c, t - (p-1)]  ->  same kernel, taps reversed + transposed
         W3T = W3.flip(0).transpose(1, 2).contiguous()
-        dh = _tconv(du, None, None, W3T, None)
+        need_sums = ctx.train or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        part = None
+        if need_sums and _tconv2_able(W3T, V):
+            # the reduction pass of the BatchNorm backward leaves through the data-gradient kernel's epilogue
+            dh, part = _tconv(du, None, None, W3T, None, want_stats=True, bwd=(z, fin))
+        else:
+            dh = _tconv(du, None, None, W3T, None)
         dz = dgamma = dbeta = dW = dbias = None
         with torch.cuda.device(dev):
-            if ctx.train:
+            if need_sums and part is None:
                 part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
                 _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
                                                  _lib.ptr(invstd), 2, _lib.ptr(scale), _lib.ptr(shift),
                                                  _lib.ptr(part), st), "bn_bwd_reduce")
+            if ctx.train:
                 tot = bn_op.bwd_finalize(part, N * L)              # (dbeta, dgamma, m1, m2)
                 dbeta, dgamma, m1, m2 = tot[0], tot[1], tot[2], tot[3]
             else:   # eval: statistics are constants, dz = scale * g
                 m1 = torch.zeros(C, device=dev)
                 m2 = torch.zeros(C, device=dev)
-                if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                if need_sums:
                     # affine gradients as nn.BatchNorm2d gives them in eval mode: with mean / invstd = the running
                     # statistics the same reduction yields (sum g, sum g * xhat) = (dbeta, dgamma)
-                    part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
-                    _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
-                                                     _lib.ptr(invstd), 2, _lib.ptr(scale), _lib.ptr(shift),
-                                                     _lib.ptr(part), st), "bn_bwd_reduce")
                     tot = bn_op.bwd_finalize(part, N * L)
                     dbeta, dgamma = tot[0], tot[1]
             dz = torch.empty_like(z)
