@@ -207,11 +207,17 @@ int p2r_stgcn_gcn_forward(int N, int T, int V, int K, const int *Lk_host,
  *   (record layout in csrc/stgcn_gcn2.hip; built by pose2room_amd/p2rnet/gcn_tables.build_stream);
  *   stream_work: scratch of the same size (the stream with the current coefficients, read by scalar loads)
  *   addend (N,64,T,V) or NULL is added to the result on the way out (the residual-branch gradient in the
- *   data-gradient launch); stats_partial [*n_partials][64][2] (optional); z == NULL queries *n_partials. */
+ *   data-gradient launch); stats_partial [*n_partials][64][2] (optional); z == NULL queries *n_partials.
+ *   bwd_u / bwd_mask / bwd_fin (all or none; data-gradient launch, stats_partial required): the statistics
+ *   epilogue then emits the reduction pass of the BatchNorm + residual + ReLU backward of the block in front
+ *   (what p2r_bn_bwd_reduce with relu = 3 computes from the stored result): per channel (sum g', sum g' * uhat),
+ *   g' = result where the ReLU mask byte bwd_mask (N,64,T,V) u8 is set, uhat = (u - mean) * invstd,
+ *   u = bwd_u (N,64,T,V) the saved input of that BatchNorm, bwd_fin [4][64] rows 0, 1 = mean, invstd. */
 int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x, const float *Wp,
                            const float *coef, const int *stream, int *stream_work,
                            const float *bias_cv, const float *addend, float *z, float *stats_partial,
-                           int *n_partials, void *stream_h);
+                           int *n_partials, const float *bwd_u, const unsigned char *bwd_mask,
+                           const float *bwd_fin, void *stream_h);
 
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
  * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over

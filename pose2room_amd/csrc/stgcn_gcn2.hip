@@ -90,11 +90,16 @@ __global__ void gcn2_fill_stream_kernel(int n, const int *__restrict__ templ, co
   work[e] = v;
 }
 
-template <int NW, int SLOTS, int VT, int LAYOUT>
+// BWD (data-gradient launches): the statistics epilogue emits the reduction pass of the BatchNorm + residual + ReLU
+// backward of the block in front (what p2r_bn_bwd_reduce with relu = 3 computes from the stored result): per channel
+// (sum g', sum g' * uhat), g' = (op(x) + addend) where the ReLU mask byte is set, uhat = (u - mean) * invstd with
+// u = bwd_u the saved input of that BatchNorm, (mean, invstd) = rows 0, 1 of bwd_fin [4][64].
+template <int NW, int SLOTS, int VT, int LAYOUT, bool BWD>
 __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
     G2Params p, const float *__restrict__ x, const float *__restrict__ Wp, const int *__restrict__ stream_g,
     const float *__restrict__ bias_cv, const float *__restrict__ addend, float *__restrict__ z,
-    float *__restrict__ stats_partial) {
+    float *__restrict__ stats_partial, const float *__restrict__ bwd_u, const unsigned char *__restrict__ bwd_mask,
+    const float *__restrict__ bwd_fin) {
   constexpr int V = VT;
   constexpr int RS = G2_F * V;                        // LDS row stride (floats): 848 == 16 (mod 32)
   constexpr int BUF = G2_CP * RS;                     // floats per phase buffer
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   extern __shared__ float lds[];
   float *rowstat = lds + 2 * BUF;                                         // [NW][64][2]
   float *bias_l = rowstat + NW * 128;                                     // [64][V] bias table (zeros without bias)
+  float *bstat = bias_l + 64 * V;                                         // [64][2] (mean, invstd) of the BWD epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,6 +118,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
 
   for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
+  if (tid < 64) {
+    bstat[2 * tid] = BWD ? bwd_fin[tid] : 0.f;
+    bstat[2 * tid + 1] = BWD ? bwd_fin[64 + tid] : 1.f;
+  }
   __syncthreads();
 
   // The work stream is read with SCALAR loads (wave-uniform addresses into read-only global memory): descriptors,
@@ -218,6 +228,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
     const float *xg = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
     float *zg = z + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
     const float *ag = addend ? addend + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
+    const float *ug = BWD ? bwd_u + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
+    const unsigned char *mg = BWD ? bwd_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * G2_F : 0;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
 
     // ---- epilogue: D[row = 16 m + 4 g + q][frame r] of joint sj[i]; statistics of the stored values.
     float *rs = rowstat + wave * 128;
-    if (stats_partial) {
+    if (!BWD && stats_partial) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -367,22 +379,83 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
           }
+        constexpr int R4 = RS / 4;                          // float4 per row (212)
+        constexpr int RIT = (R4 + 63) / 64;                 // 4
+        float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
+        unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
+        if (BWD) {   // saved activation + mask bytes of this wave's two rows: in flight across the staging barrier
+          const size_t r0 = (size_t)(16 * m + 2 * wave) * row_stride;
+          const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
+          const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              uv[rr][it] = c4 < R4 ? u4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+              mk[rr][it] = c4 < R4 ? m4[(size_t)rr * (row_stride / 4) + c4] : 0u;
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
         const float4 *arow = reinterpret_cast<const float4 *>(ag ? ag + (size_t)16 * m * row_stride : nullptr);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
+        if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
+          float4 ad[2][RIT];
+          if (arow) {
 #pragma unroll
-        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
-          const int e = it * NW * 64 + tid;
-          if (e < NV4) {
-            const int row = e / (RS / 4), c4 = e - row * (RS / 4);
-            float4 v = srow[e];
-            if (arow) {           // e.g. the gradient of the block's residual branch, added on the way out
-              const float4 ad = arow[(size_t)row * (row_stride / 4) + c4];
-              v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+              for (int it = 0; it < RIT; ++it) {
+                const int c4 = it * 64 + lane;
+                if (c4 < R4) ad[rr][it] = arow[(size_t)(2 * wave + rr) * (row_stride / 4) + c4];
+              }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, c = 16 * m + row;
+            const float mu = bstat[2 * c], is = bstat[2 * c + 1];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              if (c4 < R4) {
+                float4 v = srow[row * R4 + c4];
+                if (arow) { v.x += ad[rr][it].x; v.y += ad[rr][it].y; v.z += ad[rr][it].z; v.w += ad[rr][it].w; }
+                zrow[(size_t)row * (row_stride / 4) + c4] = v;
+                const float4 uu = uv[rr][it];
+                const unsigned mm = mk[rr][it];
+                const float g0 = (mm & 0xffu) ? v.x : 0.f, g1 = (mm & 0xff00u) ? v.y : 0.f;
+                const float g2 = (mm & 0xff0000u) ? v.z : 0.f, g3 = (mm & 0xff000000u) ? v.w : 0.f;
+                s1 += (g0 + g1) + (g2 + g3);
+                s2 = fmaf(g0, (uu.x - mu) * is, s2); s2 = fmaf(g1, (uu.y - mu) * is, s2);
+                s2 = fmaf(g2, (uu.z - mu) * is, s2); s2 = fmaf(g3, (uu.w - mu) * is, s2);
+              }
             }
-            zrow[(size_t)row * (row_stride / 4) + c4] = v;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              s1 += __shfl_xor(s1, off, 64);
+              s2 += __shfl_xor(s2, off, 64);
+            }
+            if (lane == 0) {
+              rs[2 * c] += s1;
+              rs[2 * c + 1] += s2;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+            const int e = it * NW * 64 + tid;
+            if (e < NV4) {
+              const int row = e / (RS / 4), c4 = e - row * (RS / 4);
+              float4 v = srow[e];
+              if (arow) {           // e.g. the gradient of the block's residual branch, added on the way out
+                const float4 ad = arow[(size_t)row * (row_stride / 4) + c4];
+                v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+              }
+              zrow[(size_t)row * (row_stride / 4) + c4] = v;
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,6 +479,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i)
               if (sj[i] >= 0) acc[i][m][q] += arow[sj[i] * VS];
+          }
+          if (BWD) {
+            const float mu = bstat[2 * row], is = bstat[2 * row + 1];
+            float s1 = 0.f, s2 = 0.f;
+            if (r < frames) {
+              const float *urow = ug + (size_t)row * row_stride + r * FS;
+              const unsigned char *mrow = mg + (size_t)row * row_stride + r * FS;
+#pragma unroll
+              for (int i = 0; i < SLOTS; ++i)
+                if (sj[i] >= 0) {
+                  const float gm = mrow[sj[i] * VS] ? acc[i][m][q] : 0.f;
+                  s1 += gm;
+                  s2 = fmaf(gm, (urow[sj[i] * VS] - mu) * is, s2);
+                }
+            }
+            s1 = p2r_row16_sum(s1);
+            s2 = p2r_row16_sum(s2);
+            if (r == 0) {
+              rs[2 * row] += s1;
+              rs[2 * row + 1] += s2;
+            }
           }
           if (r < frames) {
             if (LAYOUT == 0 && SLOTS == 7) {
@@ -468,8 +562,12 @@ constexpr int G2_NW = 8, G2_SLOTS = 7;
 extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x, const float *Wp,
                                       const float *coef, const int *stream, int *stream_work,
                                       const float *bias_cv, const float *addend, float *z, float *stats_partial,
-                                      int *n_partials, void *stream_h) {
+                                      int *n_partials, const float *bwd_u, const unsigned char *bwd_mask,
+                                      const float *bwd_fin, void *stream_h) {
   if (N < 0 || T <= 0 || V != 53 || K <= 0 || K >= 15 || ltot <= 0) return P2R_EINVAL;
+  const bool bwd = bwd_u != nullptr;
+  if (bwd != (bwd_mask != nullptr) || bwd != (bwd_fin != nullptr) || (bwd && !stats_partial)) return P2R_EINVAL;
+  if (bwd && (((uintptr_t)bwd_u % 16) != 0 || ((uintptr_t)bwd_mask % 4) != 0)) return P2R_EINVAL;
   if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
   G2Params p;
@@ -484,18 +582,27 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
   if (!z) return P2R_OK;
   if (!stream_work) return P2R_EINVAL;
   const size_t lds = (size_t)2 * G2_CP * G2_F * V * sizeof(float) + (size_t)G2_NW * 128 * sizeof(float) +
-                     (size_t)64 * V * sizeof(float);
+                     (size_t)64 * V * sizeof(float) + 128 * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
-  auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT>;
-  static unsigned char lds_ok[P2R_MAX_DEVICES];
-  hipError_t e = p2r_allow_big_lds(kern, lds_ok);
-  if (e != hipSuccess) return (int)e;
   const int n_stream = G2_NW * G2_WSTRIDE;
   hipLaunchKernelGGL(gcn2_fill_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, p2r_stream(stream_h), n_stream,
                      stream, coef, stream_work);
   P2R_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, stream_work, bias_cv,
-                     addend, z, stats_partial);
+  if (bwd) {
+    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT, true>;
+    static unsigned char lds_ok[P2R_MAX_DEVICES];
+    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, stream_work, bias_cv,
+                       addend, z, stats_partial, bwd_u, bwd_mask, bwd_fin);
+  } else {
+    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT, false>;
+    static unsigned char lds_ok[P2R_MAX_DEVICES];
+    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, stream_work, bias_cv,
+                       addend, z, stats_partial, nullptr, nullptr, nullptr);
+  }
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -86,11 +86,26 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
     return (y, mask) if want_mask else y
 
 
+class BNLink(object):
+    """Handshake between a fused BatchNorm (+res) + ReLU and the graph conv that consumes its output y.
+
+    When every use of y goes through one `gcn_op.graph_conv` call (st_gcn_block chains: y is the next block's
+    input and identity branch), that op's data-gradient kernel produces the whole gradient of y, so it can also
+    emit the two per-channel sums of this BatchNorm's backward from its row epilogue (`partials`), which replaces
+    the reduction pass over the gradient and the saved input.  `grad_ptr` identifies the gradient buffer the
+    sums belong to; the BatchNorm backward uses them only for that very buffer."""
+    __slots__ = ('u', 'mask', 'fin', 'partials', 'grad_ptr', 'used')
+
+    def __init__(self):
+        self.u = self.mask = self.fin = self.partials = self.grad_ptr = None
+        self.used = 0           # how many backward passes took the sums from the link (tests)
+
+
 class _FusedBNAct(Function):
     """Train-mode BatchNorm (+res) (+ReLU).  `fin` [4, C] = (mean, invstd, scale, shift) from `finalize`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, fin, relu):
+    def forward(ctx, x, weight, bias, res, fin, relu, link=None):
         x = x.contiguous()
         res_c = res.contiguous() if res is not None else None
         # the ReLU mask is kept as one byte per element, so the backward does not re-read y (4 bytes) twice
@@ -98,6 +113,9 @@ class _FusedBNAct(Function):
         ctx.save_for_backward(x, mask, fin)
         ctx.relu = relu
         ctx.has_res = res is not None
+        ctx.link = link if relu else None
+        if ctx.link is not None:
+            link.u, link.mask, link.fin = x, mask, fin
         return y
 
     @staticmethod
@@ -109,11 +127,18 @@ class _FusedBNAct(Function):
         N, C, L = _rows(x)
         dev = x.device
         lib = _lib.lib()
-        part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
-                                             _lib.ptr(invstd), mode, None, None, _lib.ptr(part),
-                                             _lib.current_stream(dev)), "bn_bwd_reduce")
+        link, part = ctx.link, None
+        if link is not None:
+            if link.partials is not None and link.grad_ptr == dy.data_ptr():
+                part = link.partials        # emitted by the kernel that wrote dy (gcn_op._GraphConv.backward)
+                link.used += 1
+            link.partials = link.grad_ptr = None
+        if part is None:
+            part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
+                                                 _lib.ptr(invstd), mode, None, None, _lib.ptr(part),
+                                                 _lib.current_stream(dev)), "bn_bwd_reduce")
         tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
@@ -122,7 +147,7 @@ class _FusedBNAct(Function):
                                             _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
                                             mode, None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
-        return dx, tot[1], tot[0], dres, None, None
+        return dx, tot[1], tot[0], dres, None, None, None
 
 
 class _EvalBNAct(Function):
@@ -156,12 +181,16 @@ def supported(x, bn):
     return x.is_cuda and x.dtype == torch.float32 and bn.affine and bn.track_running_stats and x.dim() >= 3
 
 
-def fused_bn_act(x, bn, res=None, relu=True, stats=None):
-    """stats: optional kernel partials [P, C, 2] of x (see `moments`) replacing the statistics pass."""
+def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None):
+    """stats: optional kernel partials [P, C, 2] of x (see `moments`) replacing the statistics pass.
+    link: a `BNLink` to hang on the result (train mode) for the graph conv that consumes it."""
     if bn.training:
         part = _stats_partial(x.contiguous()) if stats is None else stats
         fin = finalize(part, x.numel() // x.shape[1], bn)
-        return _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu)
+        y = _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu, link)
+        if link is not None and relu:
+            y._p2r_bn_link = link
+        return y
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     shift = bn.bias - bn.running_mean * scale

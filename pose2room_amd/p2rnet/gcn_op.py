@@ -68,7 +68,9 @@ def permute_planes(W3):
     return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()     # (k, ph, m, g, r, s)
 
 
-def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None):
+def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None):
+    """bwd = (u, mask, fin): data-gradient launch whose statistics epilogue is the reduction pass of the
+    BatchNorm + residual + ReLU backward of the block in front (implies want_stats; see bn_op.BNLink)."""
     N, C, T, V = x.shape
     z = torch.empty_like(x)
     lib = _lib.lib()
@@ -79,15 +81,18 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
         work = torch.empty_like(stream)       # the stream with this call's coefficients (scalar-loaded by the kernel)
+        bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
         _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
                                               _lib.ptr(stream), _lib.ptr(work), _lib.ptr(bias_cv), _lib.ptr(addend),
-                                              _lib.ptr(z), _lib.ptr(part), None, st), "stgcn_gcn2_forward")
+                                              _lib.ptr(z), _lib.ptr(part), None, _lib.ptr(bu), _lib.ptr(bm),
+                                              _lib.ptr(bf), st), "stgcn_gcn2_forward")
     return (z, part) if want_stats else z
 
 
 class _GraphConv(Function):
     @staticmethod
-    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False):
+    def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False,
+                bn_link=None):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
@@ -101,6 +106,7 @@ class _GraphConv(Function):
                                want_stats)
         ctx.save_for_backward(x, W, coef_c, coef_r)
         ctx.tables = tables
+        ctx.bn_link = bn_link
         ctx.n_out = 2 if want_stats else 1
         if want_stats:
             ctx.mark_non_differentiable(out[1])
@@ -124,8 +130,16 @@ class _GraphConv(Function):
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
             if tables.V == 53:
+                link = ctx.bn_link
+                use_link = link is not None and link.u is not None and link.u.shape == x.shape
                 dx = _gcn2_forward(dz, permute_planes(W.view(K, C, C).transpose(1, 2)), coef_r.contiguous(),
-                                   t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None)
+                                   t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,
+                                   want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None)
+                if use_link:
+                    # dx is the whole gradient of the previous block's output: its BatchNorm backward takes the
+                    # two per-channel sums from here instead of a pass over dx and its saved input
+                    dx, link.partials = dx
+                    link.grad_ptr = dx.data_ptr()
                 dres = None
             else:
                 Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
@@ -164,7 +178,7 @@ class _GraphConv(Function):
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
         if dres is not None:
             dx = dres if dx is None else dx + dres
-        return dx, dW, None, dcoef_r, dbias, None, None, None
+        return dx, dW, None, dcoef_r, dbias, None, None, None, None
 
 
 def supported(x, weight, A):
@@ -173,12 +187,15 @@ def supported(x, weight, A):
             and A.shape[1] <= 64)
 
 
-def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False):
+def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None):
     """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
     with_residual: additionally return x itself (last output) for the caller's identity branch; its gradient is then
     added inside the data-gradient kernel.
     want_stats: also return the kernel's per-workgroup (sum, sum of squares) partials of z per channel
-    ([P,64,2], see bn_op.moments) -- the batch statistics of the BatchNorm that consumes z."""
+    ([P,64,2], see bn_op.moments) -- the batch statistics of the BatchNorm that consumes z.
+    bn_link: the bn_op.BNLink of the fused BatchNorm + residual + ReLU that produced x, when every use of x goes
+    through this call (x and, with_residual, the identity branch): the data-gradient kernel then also emits the
+    reduction pass of that BatchNorm's backward."""
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)
@@ -188,4 +205,4 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
         bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
     else:
         bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
-    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual)
+    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual, bn_link)

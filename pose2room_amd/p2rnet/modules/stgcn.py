@@ -40,8 +40,9 @@ class STGCN(nn.Module):
             [st_gcn_block(64, 64, kernel_size, 1) for _ in range(5)])
         from ..gcn_op import GraphTables
         tables = GraphTables(self.graph.A)     # sparse form of the skeleton adjacency for the fused kernels
-        for blk in self.st_gcn_networks:
+        for i, blk in enumerate(self.st_gcn_networks):
             blk.gcn.tables = tables
+            blk.chain_input = i > 0     # forward(): block i is the only consumer of block i-1's output
         self.conv_joint = nn.Conv1d(cfg.dataset_config.joint_num * 64, out_channels, kernel_size=1)
         self.edge_importance = nn.ParameterList(
             [nn.Parameter(torch.ones(self.A.size())) for _ in self.st_gcn_networks])

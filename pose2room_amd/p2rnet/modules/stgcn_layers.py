@@ -111,16 +111,17 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A, want_stats=False, with_residual=False):
+    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None):
         """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
         following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv).  with_residual (same
-        path): x itself comes back as the last element of the tuple, for the caller's identity branch."""
+        path): x itself comes back as the last element of the tuple, for the caller's identity branch.
+        bn_link: see gcn_op.graph_conv."""
         assert A.size(0) == self.kernel_size
         if self.tables is not None and self.fused:
             from .. import gcn_op
             if gcn_op.supported(x, self.conv.weight, A):
                 return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats,
-                                         with_residual), A
+                                         with_residual, bn_link), A
         assert not want_stats and not with_residual
         y = self.conv(x)
         n, kc, t, v = y.size()
@@ -165,6 +166,8 @@ class st_gcn_block(nn.Module):
 
     fused_bn = True   # BatchNorm + residual + ReLU on the fused HIP kernels (GPU tensors)
     fused_tconv = True   # BatchNorm + ReLU + temporal conv in one kernel
+    chain_input = False  # set by the owner when this block is the ONLY consumer of its input (the previous block's
+                         # output): the data-gradient kernel then also serves that block's BatchNorm backward
 
     def forward(self, x, A):
         res = self.residual(x)
@@ -178,12 +181,13 @@ class st_gcn_block(nn.Module):
                 if self.residual is _iden and x.requires_grad:
                     # identity branch routed through the graph-conv op: its gradient is added inside the
                     # data-gradient kernel instead of a separate accumulation pass over the activation
-                    (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True)
+                    in_link = getattr(x, '_p2r_bn_link', None) if self.chain_input else None
+                    (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True, bn_link=in_link)
                 else:
                     (z, zstats), A = self.gcn(x, A, want_stats=True)
                 u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True)
                 res_t = res if torch.is_tensor(res) else None
-                return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats), A
+                return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats, link=bn_op.BNLink()), A
             x, A = self.gcn(x, A)
             if bn_op.supported(x, self.tcn[0]):
                 if self.fused_tconv and tconv_op.supported(x, self.tcn[0], self.tcn[2]):

@@ -118,3 +118,51 @@ def test_adjacency_gradient_reaches_zero_valued_entries(dev):
     assert (ia.grad.double() - ib.grad).abs().max().item() <= 2e-4 * scale
     zeroed = imp == 0
     assert (ib.grad[zeroed & (At != 0)].abs() > 1e-3 * scale).any()      # those gradients are not trivially zero
+
+
+@pytest.mark.parametrize("N,T", [(2, 40), (3, 130), (1, 7)])
+def test_chained_blocks_bn_backward_from_the_data_gradient_epilogue(dev, N, T):
+    """Two chained st_gcn_blocks: with `chain_input` the second block's graph-conv data-gradient kernel emits the
+    reduction sums of the first block's BatchNorm + residual + ReLU backward (bn_op.BNLink).  Gradients must equal
+    those of the separate reduction pass, and the link must actually have been used."""
+    import copy
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph, st_gcn_block
+    from pose2room_amd.p2rnet import gcn_op
+    A = torch.tensor(Graph().A, dtype=torch.float32, device=dev)
+    tables = gcn_op.GraphTables(Graph().A)
+    torch.manual_seed(7 + T)
+    blocks = torch.nn.ModuleList([st_gcn_block(64, 64, (3, A.shape[0]), 1) for _ in range(2)]).to(dev)
+    for b in blocks:
+        b.gcn.tables = tables
+        for bn in (b.tcn[0], b.tcn[3]):
+            bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(blocks)
+    x0 = torch.randn(N, 64, T, A.shape[1], device=dev)
+    w = torch.randn(N, 64, T, A.shape[1], device=dev)
+    links = []
+
+    def run(net, chain):
+        x = x0.clone().requires_grad_(True)
+        h = x + 0.0                       # a non-leaf input, as in the model
+        for i, b in enumerate(net):
+            b.chain_input = chain and i > 0
+            h, _ = b(h, A)
+            if chain and hasattr(h, '_p2r_bn_link'):
+                links.append(h._p2r_bn_link)
+        (h * w).sum().backward()
+        return x.grad, {k: p.grad for k, p in net.named_parameters()}
+
+    gx_a, gp_a = run(blocks, True)
+    gx_b, gp_b = run(ref, False)
+    assert links and links[0].used == 1, "the BatchNorm backward did not take its sums from the link"
+
+    def close(a, b, name):
+        scale = max(b.abs().max().item(), 1.0)
+        assert (a - b).abs().max().item() <= 2e-4 * scale, f"{name}: {(a - b).abs().max().item()} vs scale {scale}"
+    close(gx_a, gx_b, "dx")
+    for k in gp_b:
+        # the gradient of a conv bias in front of a train-mode BatchNorm is zero in exact arithmetic: what both
+        # paths return there is rounding noise of the summation order
+        if k.endswith('gcn.conv.bias') or k.endswith('tcn.2.bias'):
+            continue
+        close(gp_a[k], gp_b[k], k)

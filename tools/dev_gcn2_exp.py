@@ -36,7 +36,7 @@ for path in sorted(glob.glob(os.path.join(here, 'g2_*.so'))):
         def call():
             rc = lib.p2r_stgcn_gcn2_forward(N, T, V, K, coef.shape[0], _lib.ptr(x), _lib.ptr(Wp),
                                             _lib.ptr(coef), _lib.ptr(sched), _lib.ptr(work), None, None, _lib.ptr(z), _lib.ptr(part), None,
-                                            _lib.current_stream(dev))
+                                            None, None, None, _lib.current_stream(dev))
             assert rc == 0, rc
         for _ in range(3):
             call()
