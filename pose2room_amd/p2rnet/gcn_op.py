@@ -92,21 +92,22 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
 class _GraphConv(Function):
     @staticmethod
     def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False,
-                bn_link=None):
+                bn_link=None, wp_f=None, wp_b=None):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
         x = x.contiguous()
         W = weight.contiguous()
         if tables.V == 53:      # second-generation kernel (csrc/stgcn_gcn2.hip)
-            out = _gcn2_forward(x, permute_planes(W.view(tables.K, 64, 64)), coef_c.contiguous(), t['stream_c'],
-                                bias_cv.contiguous(), tables, want_stats)
+            out = _gcn2_forward(x, wp_f if wp_f is not None else permute_planes(W.view(tables.K, 64, 64)),
+                                coef_c.contiguous(), t['stream_c'], bias_cv.contiguous(), tables, want_stats)
         else:
             out = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables,
                                want_stats)
         ctx.save_for_backward(x, W, coef_c, coef_r)
         ctx.tables = tables
         ctx.bn_link = bn_link
+        ctx.wp_b = wp_b            # planes of the data gradient, already in kernel order (prepare_chain), or None
         ctx.n_out = 2 if want_stats else 1
         if want_stats:
             ctx.mark_non_differentiable(out[1])
@@ -132,7 +133,8 @@ class _GraphConv(Function):
             if tables.V == 53:
                 link = ctx.bn_link
                 use_link = link is not None and link.u is not None and link.u.shape == x.shape
-                dx = _gcn2_forward(dz, permute_planes(W.view(K, C, C).transpose(1, 2)), coef_r.contiguous(),
+                wp_b = ctx.wp_b if ctx.wp_b is not None else permute_planes(W.view(K, C, C).transpose(1, 2))
+                dx = _gcn2_forward(dz, wp_b, coef_r.contiguous(),
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,
                                    want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None)
                 if use_link:
@@ -178,7 +180,7 @@ class _GraphConv(Function):
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
         if dres is not None:
             dx = dres if dx is None else dx + dres
-        return dx, dW, None, dcoef_r, dbias, None, None, None, None
+        return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None
 
 
 def supported(x, weight, A):
@@ -187,7 +189,7 @@ def supported(x, weight, A):
             and A.shape[1] <= 64)
 
 
-def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None):
+def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None, prepared=None):
     """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
     with_residual: additionally return x itself (last output) for the caller's identity branch; its gradient is then
     added inside the data-gradient kernel.
@@ -195,10 +197,15 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
     ([P,64,2], see bn_op.moments) -- the batch statistics of the BatchNorm that consumes z.
     bn_link: the bn_op.BNLink of the fused BatchNorm + residual + ReLU that produced x, when every use of x goes
     through this call (x and, with_residual, the identity branch): the data-gradient kernel then also emits the
-    reduction pass of that BatchNorm's backward."""
+    reduction pass of that BatchNorm's backward.
+    prepared: this block's `BlockParams` from `prepare_chain` (coefficient tables, bias table and kernel-order
+    planes computed for all blocks at once); Aeff is then not looked at."""
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)
+    if prepared is not None:
+        return _GraphConv.apply(x, w2, prepared.coef_c, prepared.coef_r, prepared.bias_cv, tables, want_stats,
+                                with_residual, bn_link, prepared.gcn_wp_f, prepared.gcn_wp_b)
     coef_c = gcn_tables.coefficients(Aeff.detach(), t['gidx_c'])      # forward lists (values only)
     coef_r = gcn_tables.coefficients(Aeff, t['gidx_r'])               # backward lists; carries the gradient to Aeff
     if bias is not None:
@@ -206,3 +213,53 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
     else:
         bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
     return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual, bn_link)
+
+
+class BlockParams(object):
+    """One st_gcn_block's share of `prepare_chain`."""
+    __slots__ = ('Aeff', 'coef_c', 'coef_r', 'bias_cv', 'gcn_wp_f', 'gcn_wp_b', 'tcn_wp_f', 'tcn_wp_b')
+
+
+def prepare_chain(blocks, A, importances, tables):
+    """The small per-block parameter transforms of the fused path, done for ALL blocks of an ST-GCN stack at once:
+    `A * edge_importance`, the two coefficient tables, the bias table, and the kernel-order copies of the graph-conv
+    planes and temporal-conv taps (forward and data-gradient forms).  Per block these are ~25 launches of a few
+    microseconds each way; batched they are ~20 for the whole stack.  Same arithmetic, same autograd graph up to
+    stack / unbind nodes.  Requires every block to be 64 -> 64 with K planes of 64 x 64 and a (3,1) temporal conv."""
+    B = len(blocks)
+    K, V = tables.K, tables.V
+    dev = A.device
+    t = tables.on(dev)
+    Aeff = A.unsqueeze(0) * torch.stack(list(importances))                      # (B,K,V,V)
+    flat = Aeff.reshape(B, -1)
+
+    def coef(flat_, gidx):
+        safe = gidx.clamp(min=0).reshape(-1)
+        vals = flat_.index_select(1, safe).view(B, *gidx.shape)
+        return torch.where(gidx >= 0, vals, torch.zeros((), dtype=flat_.dtype, device=dev))
+
+    coef_c = coef(flat.detach(), t['gidx_c'])                                   # values only
+    coef_r = coef(flat, t['gidx_r'])                                            # carries the gradient to Aeff
+    biases = [b.gcn.conv.bias for b in blocks]
+    if all(b is not None for b in biases):
+        bias_cv = torch.bmm(torch.stack(biases).view(B, K, 64).transpose(1, 2), Aeff.sum(dim=2))   # (B,64,V)
+    else:
+        assert all(b is None for b in biases)
+        bias_cv = torch.zeros(B, 64, V, dtype=A.dtype, device=dev)
+    with torch.no_grad():
+        W = torch.stack([b.gcn.conv.weight.view(K, 64, 64) for b in blocks])   # (B,K,64 rows,64 cols)
+        # forward: Wp[k][ph][m][16g+r][s] = W_k[16m+r][16ph+4s+g];  data gradient: the same of W_k^T
+        gcn_f = W.view(B, K, 4, 16, 4, 4, 4).permute(0, 1, 4, 2, 6, 3, 5).contiguous()     # (b,k,ph,m,g,r,s)
+        gcn_b = W.view(B, K, 4, 4, 4, 4, 16).permute(0, 1, 2, 5, 4, 6, 3).contiguous()     # rows = (ph,s,g), cols = (m,r)
+        Wt = torch.stack([b.tcn[2].weight.view(64, 64, 3) for b in blocks])     # (B, c, ci, tap)
+        tcn_f = Wt.view(B, 4, 16, 4, 4, 4, 3).permute(0, 6, 3, 1, 5, 2, 4).contiguous()    # (b,tap,ph,m,g,r,s)
+        # data gradient: tap p' uses W[2 - p']^T
+        tcn_b = Wt.flip(-1).view(B, 4, 4, 4, 4, 16, 3).permute(0, 6, 1, 4, 3, 5, 2).contiguous()   # rows = (ph,s,g)
+    out = []
+    A_b, cc, cr, bc = Aeff.unbind(0), coef_c.unbind(0), coef_r.unbind(0), bias_cv.unbind(0)
+    for i in range(B):
+        p = BlockParams()
+        p.Aeff, p.coef_c, p.coef_r, p.bias_cv = A_b[i], cc[i], cr[i], bc[i]
+        p.gcn_wp_f, p.gcn_wp_b, p.tcn_wp_f, p.tcn_wp_b = gcn_f[i], gcn_b[i], tcn_f[i], tcn_b[i]
+        out.append(p)
+    return out

@@ -128,8 +128,16 @@ class STGCN(nn.Module):
         seed_inds = self._select_seeds(input_joints[:, :, self.origin_joint_id])
 
         x = self.embed(input_joints)
-        for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
-            x, _ = gcn(x, self.A * importance)
+        blocks = self.st_gcn_networks
+        tables = blocks[0].gcn.tables
+        if tables is not None and tables.V == 53 and all(b.chainable(x, self.A) for b in blocks):
+            # fused train-mode path: the per-block parameter transforms are computed for all blocks at once
+            from ..gcn_op import prepare_chain
+            for gcn, prep in zip(blocks, prepare_chain(blocks, self.A, self.edge_importance, tables)):
+                x, _ = gcn(x, prep.Aeff, prepared=prep)
+        else:
+            for gcn, importance in zip(blocks, self.edge_importance):
+                x, _ = gcn(x, self.A * importance)
 
         seed_skeleton = torch.gather(
             input_joints, 1, seed_inds[:, :, None, None].expand(n_batch, self.n_seeds, n_joints, n_dim))

@@ -111,18 +111,18 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None):
+    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None, prepared=None):
         """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
         following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv).  with_residual (same
         path): x itself comes back as the last element of the tuple, for the caller's identity branch.
-        bn_link: see gcn_op.graph_conv."""
+        bn_link, prepared: see gcn_op.graph_conv."""
         assert A.size(0) == self.kernel_size
         if self.tables is not None and self.fused:
             from .. import gcn_op
             if gcn_op.supported(x, self.conv.weight, A):
                 return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats,
-                                         with_residual, bn_link), A
-        assert not want_stats and not with_residual
+                                         with_residual, bn_link, prepared), A
+        assert not want_stats and not with_residual and prepared is None
         y = self.conv(x)
         n, kc, t, v = y.size()
         y = y.view(n, self.kernel_size, kc // self.kernel_size, t, v)
@@ -169,23 +169,34 @@ class st_gcn_block(nn.Module):
     chain_input = False  # set by the owner when this block is the ONLY consumer of its input (the previous block's
                          # output): the data-gradient kernel then also serves that block's BatchNorm backward
 
-    def forward(self, x, A):
+    def chainable(self, x, A):
+        """True when forward() takes the fully fused train-mode path for this input."""
+        if not (self.fused_bn and x.is_cuda and self.tcn[4].p == 0):
+            return False
+        from .. import bn_op, gcn_op, tconv_op
+        return (self.training and self.fused_tconv and self.gcn.tables is not None and self.gcn.fused
+                and gcn_op.supported(x, self.gcn.conv.weight, A) and bn_op.supported(x, self.tcn[0])
+                and tconv_op.supported(x, self.tcn[0], self.tcn[2]))
+
+    def forward(self, x, A, prepared=None):
+        """prepared: this block's gcn_op.BlockParams (only valid when `chainable`); A is then prepared.Aeff."""
         res = self.residual(x)
         if self.fused_bn and x.is_cuda and self.tcn[4].p == 0:
             from .. import bn_op, gcn_op, tconv_op
             # kernel epilogues hand the batch statistics to the BatchNorm that follows (train mode)
-            chain = (self.training and self.fused_tconv and self.gcn.tables is not None and self.gcn.fused
-                     and gcn_op.supported(x, self.gcn.conv.weight, A) and bn_op.supported(x, self.tcn[0])
-                     and tconv_op.supported(x, self.tcn[0], self.tcn[2]))
+            chain = self.chainable(x, A)
+            assert chain or prepared is None
             if chain:
                 if self.residual is _iden and x.requires_grad:
                     # identity branch routed through the graph-conv op: its gradient is added inside the
                     # data-gradient kernel instead of a separate accumulation pass over the activation
                     in_link = getattr(x, '_p2r_bn_link', None) if self.chain_input else None
-                    (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True, bn_link=in_link)
+                    (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True, bn_link=in_link,
+                                                   prepared=prepared)
                 else:
-                    (z, zstats), A = self.gcn(x, A, want_stats=True)
-                u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True)
+                    (z, zstats), A = self.gcn(x, A, want_stats=True, prepared=prepared)
+                wp = (prepared.tcn_wp_f, prepared.tcn_wp_b) if prepared is not None and z.shape[3] == 53 else None
+                u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True, wp=wp)
                 res_t = res if torch.is_tensor(res) else None
                 return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats, link=bn_op.BNLink()), A
             x, A = self.gcn(x, A)

@@ -32,15 +32,17 @@ def _tconv2_able(W3, V):
     return W3.shape[0] == 3 and V == 53
 
 
-def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None):
+def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
     """bwd = (z, fin): data-gradient launch whose statistics epilogue is the reduction pass of the BatchNorm + ReLU
-    backward in front (second-generation kernel only; implies want_stats)."""
+    backward in front (second-generation kernel only; implies want_stats).  Wp: W3 already in the kernel's
+    A-operand order (`_permute_taps`), W3 may then be None."""
     N, C, T, V = x.shape
     out = torch.empty_like(x)
     lib = _lib.lib()
     part = None
-    if _tconv2_able(W3, V):          # second-generation kernel
-        Wp = _permute_taps(W3)
+    if Wp is not None or _tconv2_able(W3, V):          # second-generation kernel
+        if Wp is None:
+            Wp = _permute_taps(W3)
         bz, bfin = (bwd[0], bwd[1].contiguous()) if bwd is not None else (None, None)
         with torch.cuda.device(x.device):
             st = _lib.current_stream(x.device)
@@ -70,12 +72,22 @@ class _BNReLUTConv(Function):
     constants)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, fin, weight, bias, train, want_stats=False):
+    def forward(ctx, z, gamma, beta, fin, weight, bias, train, want_stats=False, wp_f=None, wp_b=None):
+        """wp_f / wp_b: the taps in kernel order for the forward and the data-gradient launch (gcn_op.prepare_chain);
+        only for the (3,1) conv over 53 joints."""
         z = z.contiguous()
         taps = weight.numel() // (64 * 64)
-        W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
-        out = _tconv(z, fin[2], fin[3], W3, bias.contiguous() if bias is not None else None, want_stats)
-        ctx.save_for_backward(z, fin, W3)
+        if wp_f is not None:
+            assert taps == 3 and z.shape[3] == 53 and wp_b is not None
+            W3 = None
+            out = _tconv(z, fin[2], fin[3], None, bias.contiguous() if bias is not None else None, want_stats, Wp=wp_f)
+            ctx.save_for_backward(z, fin)
+        else:
+            W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
+            out = _tconv(z, fin[2], fin[3], W3, bias.contiguous() if bias is not None else None, want_stats)
+            ctx.save_for_backward(z, fin, W3)
+        ctx.wp_b = wp_b
+        ctx.taps = taps
         ctx.train = train
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
@@ -85,7 +97,10 @@ class _BNReLUTConv(Function):
 
     @staticmethod
     def backward(ctx, du, _dstats=None):
-        z, fin, W3 = ctx.saved_tensors
+        if ctx.wp_b is not None:
+            (z, fin), W3 = ctx.saved_tensors, None
+        else:
+            z, fin, W3 = ctx.saved_tensors
         mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         du = du.contiguous()
         N, C, T, V = z.shape
@@ -94,14 +109,15 @@ class _BNReLUTConv(Function):
         lib = _lib.lib()
         st = _lib.current_stream(dev)
         # dh[ci, t] = sum_p W[p][c][ci] du[c, t - (p-1)]  ->  same kernel, taps reversed + transposed
-        W3T = W3.flip(0).transpose(1, 2).contiguous()
+        wp_b = ctx.wp_b
+        W3T = W3.flip(0).transpose(1, 2).contiguous() if wp_b is None else None
         need_sums = ctx.train or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         part = None
-        if need_sums and _tconv2_able(W3T, V):
+        if need_sums and (wp_b is not None or _tconv2_able(W3T, V)):
             # the reduction pass of the BatchNorm backward leaves through the data-gradient kernel's epilogue
-            dh, part = _tconv(du, None, None, W3T, None, want_stats=True, bwd=(z, fin))
+            dh, part = _tconv(du, None, None, W3T, None, want_stats=True, bwd=(z, fin), Wp=wp_b)
         else:
-            dh = _tconv(du, None, None, W3T, None)
+            dh = _tconv(du, None, None, W3T, None, Wp=wp_b)
         dz = dgamma = dbeta = dW = dbias = None
         with torch.cuda.device(dev):
             if need_sums and part is None:
@@ -125,7 +141,7 @@ class _BNReLUTConv(Function):
                                             _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
                                             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
                        "bn_bwd_apply")
-            taps = W3.shape[0]
+            taps = ctx.taps
             part = torch.empty((_N_BLOCKS, taps, 64, 64), dtype=torch.float32, device=dev)
             bpart = torch.empty((_N_BLOCKS, 64), dtype=torch.float32, device=dev) if ctx.has_bias else None
             _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
@@ -135,7 +151,7 @@ class _BNReLUTConv(Function):
             dW = part.sum(0).permute(1, 2, 0).reshape(-1).view(ctx.wshape)
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
                 dbias = bpart.double().sum(0).float()
-        return dz, dgamma, dbeta, None, dW, dbias, None, None
+        return dz, dgamma, dbeta, None, dW, dbias, None, None, None, None
 
 
 def supported(z, bn, conv):
@@ -195,13 +211,15 @@ def embed3(x, conv):
     return _Embed3.apply(x, conv.weight, conv.bias)
 
 
-def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False):
+def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False, wp=None):
     """stats: kernel partials [P,64,2] of z from its producer (bn_op.moments) instead of a statistics pass;
-    want_stats: return (u, partials of u) for the BatchNorm that consumes u."""
+    want_stats: return (u, partials of u) for the BatchNorm that consumes u;
+    wp: (forward, data-gradient) taps in kernel order from gcn_op.prepare_chain (train mode)."""
     if bn.training:
         part = bn_op._stats_partial(z.contiguous()) if stats is None else stats
         fin = bn_op.finalize(part, z.numel() // z.shape[1], bn)     # also updates the running statistics
-        return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats)
+        wp_f, wp_b = wp if wp is not None else (None, None)
+        return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats, wp_f, wp_b)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale]).detach()
