@@ -91,8 +91,11 @@ def load_optimizer(config, net):
     if not groups:       # a bare module without children / specs
         groups = [{'params': [p for p in net.parameters() if p.requires_grad]}]
     if adam:
+        # parameters on the GPU: the fused implementation (one multi-tensor kernel per chunk of parameters instead of
+        # ~10 elementwise passes over the parameter list; same update rule)
+        on_gpu = all(p.is_cuda for g in groups for p in g['params'])
         return torch.optim.AdamW(groups, lr=float(spec['lr']), betas=tuple(spec['betas']), eps=float(spec['eps']),
-                                 weight_decay=float(spec['weight_decay']))
+                                 weight_decay=float(spec['weight_decay']), fused=True if on_gpu else None)
     return torch.optim.SGD(groups, lr=float(spec['lr']), momentum=0.9)
 
 
