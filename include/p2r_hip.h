@@ -318,7 +318,8 @@ int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, c
                                 const float *shift, const float *dout, int n_blocks,
                                 float *dw_partial, float *dbias_partial, void *stream);
 
-/* Second generation of p2r_stgcn_tconv_forward for taps = 3, V = 53 (csrc/stgcn_tconv2.hip): MFMA n-tile = 16
+/* Second generation of p2r_stgcn_tconv_forward for V = 53, taps = 3 (temporal conv) or 1 (the pointwise
+ * 64 -> 64 convolutions of the embedding MLPs; Wp [1][4][4][64][4]) (csrc/stgcn_tconv2.hip): MFMA n-tile = 16
  * frames of one joint, channel phases double-buffered in LDS by LDS-DMA, persistent workgroups, input transform
  * applied on the B operand.  Wp [3][4][4][64][4]: Wp[p][ph][m][16 g + r][s] = W[p][16 m + r][16 ph + 4 s + g].
  * scale / shift both NULL = no input transform (the data-gradient launch, with flipped / transposed taps).
@@ -327,7 +328,7 @@ int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, c
  * then emits the reduction pass of the BatchNorm + ReLU backward of the layer in front (what p2r_bn_bwd_reduce
  * with relu = 2 computes from `out`): per channel (sum g', sum g' * zhat), g' = out where scale*z + shift > 0,
  * zhat = (z - mean) * invstd, z = bwd_z (N,64,T,53), bwd_fin [4][64] = (mean, invstd, scale, shift). */
-int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
+int p2r_stgcn_tconv2_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
                              const float *Wp, const float *bias, float *out, float *stats_partial,
                              int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
 

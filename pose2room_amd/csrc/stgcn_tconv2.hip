@@ -32,7 +32,7 @@ constexpr int T2_CP = 16;           // channels per phase
 constexpr int T2_NPH = 4;
 constexpr int T2_NW = 8;            // waves per workgroup
 constexpr int T2_SLOTS = 7;         // joints per wave (consecutive)
-constexpr int T2_TAPS = 3;
+constexpr int T2_MAXTAPS = 3;
 
 struct T2Params {
   int T, tiles_per_seq, total_tiles;
@@ -60,7 +60,9 @@ __device__ __forceinline__ void t2_dma4(const float *src, float *lds_dst) {
 // of the layer in front instead -- per channel sum g' and sum g' * zhat with g' = out where relu'(scale*z+shift),
 // zhat = (z - mean) * invstd, z = bwd_z (the saved activation), constants from bwd_fin [4][64] = (mean, invstd,
 // scale, shift).  The rows leave through LDS anyway; the extra traffic is one read of z.
-template <int VT, bool XFORM, bool BWD>
+// TAPS = 3: the (3,1) temporal convolution; TAPS = 1: a pointwise 64 -> 64 convolution over the same layout (the
+// embedding MLPs): no halo frames, one plane.
+template <int VT, bool XFORM, bool BWD, int TAPS>
 __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
     T2Params p, const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
   const float fillv = XFORM ? __int_as_float(0x7fc00000) : 0.f;   // outside the sequence: NaN -> relu gives the zero padding
 
   // per-lane read positions inside a buffer for (tap, k-step s): channel 4s+g, frame r+tap-1 (halo for -1 / 16)
-  int rd[T2_TAPS][4];
+  int rd[TAPS][4];
 #pragma unroll
-  for (int tp = 0; tp < T2_TAPS; ++tp) {
-    const int f = r + tp - 1;
+  for (int tp = 0; tp < TAPS; ++tp) {
+    const int f = r + tp - (TAPS - 1) / 2;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = 4 * s + g;
@@ -118,7 +120,9 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
   constexpr int PIECES4 = (MAIN + 63) / 64;           // 212
   constexpr int PW4 = (PIECES4 + NW - 1) / NW;        // 27 per wave
   constexpr int PIECESH = (HALO + 63) / 64;           // 27
-  constexpr int PWH = (PIECESH + NW - 1) / NW;        // 4 per wave
+  constexpr int PWH = TAPS > 1 ? (PIECESH + NW - 1) / NW : 0;   // 4 per wave; no halo for a single tap
+  constexpr int MPT = (PW16 + TAPS - 1) / TAPS;       // main / halo pieces issued per tap visit
+  constexpr int HPT = TAPS > 1 ? (PWH + TAPS - 1) / TAPS : 0;
   // main part: piece_i in [0, PW16); frames >= `frames` of a ragged tile are filled, not copied
   auto dma_main = [&](int piece_i, float *buf, const float *xrow0, int frames) {
     if (p.vec && frames == T2_F) {
@@ -227,15 +231,16 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
             cur4[e] = v;
           }
         }
-        for (int e = tid; e < HALO; e += NW * 64) {
-          const int ch = T2_CP * ph + e / HRS;
-          cur[MAIN + e] = fmaxf(fmaf(cur[MAIN + e], aff[2 * ch], aff[2 * ch + 1]), 0.f);
-        }
+        if (TAPS > 1)
+          for (int e = tid; e < HALO; e += NW * 64) {
+            const int ch = T2_CP * ph + e / HRS;
+            cur[MAIN + e] = fmaxf(fmaf(cur[MAIN + e], aff[2 * ch], aff[2 * ch + 1]), 0.f);
+          }
         __syncthreads();
       }
 
 #pragma unroll 1
-      for (int tp = 0; tp < T2_TAPS; ++tp) {
+      for (int tp = 0; tp < TAPS; ++tp) {
         float a[4][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -243,12 +248,12 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
           for (int s = 0; s < 4; ++s) a[m][s] = a_nxt[m][s];
         {   // prefetch the A operands of the next (tap, phase); a share of the DMA pieces of the next slice
           int ntp = tp + 1, nph = ph;
-          if (ntp == T2_TAPS) { ntp = 0; nph = (ph + 1) & (T2_NPH - 1); }
+          if (ntp == TAPS) { ntp = 0; nph = (ph + 1) & (T2_NPH - 1); }
           load_a(ntp, nph);
         }
         if (copy) {
-          for (int i = tp * 3; i < min(tp * 3 + 3, PW16); ++i) dma_main(i, buf_nxt, src, sfr);
-          for (int i = tp * 2; i < min(tp * 2 + 2, PWH); ++i) dma_halo(i, buf_nxt, src, slo, shi);
+          for (int i = tp * MPT; i < min(tp * MPT + MPT, PW16); ++i) dma_main(i, buf_nxt, src, sfr);
+          for (int i = tp * HPT; i < min(tp * HPT + HPT, PWH); ++i) dma_halo(i, buf_nxt, src, slo, shi);
         }
         const float *b0 = bufc + rd[tp][0] + j0, *b1 = bufc + rd[tp][1] + j0, *b2 = bufc + rd[tp][2] + j0,
                     *b3 = bufc + rd[tp][3] + j0;
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
         }
       }
       if (copy) {
-        for (int i = T2_TAPS * 3; i < PW16; ++i) dma_main(i, buf_nxt, src, sfr);
-        for (int i = T2_TAPS * 2; i < PWH; ++i) dma_halo(i, buf_nxt, src, slo, shi);
+        for (int i = TAPS * MPT; i < PW16; ++i) dma_main(i, buf_nxt, src, sfr);
+        for (int i = TAPS * HPT; i < PWH; ++i) dma_halo(i, buf_nxt, src, slo, shi);
       }
     }
 
@@ -430,10 +435,24 @@ __global__ __launch_bounds__(T2_NW * 64, 2) void tconv2_kernel(
 // of tap dt = p - 1 (the same permutation as the graph conv's planes); scale / shift [64] or both NULL (input
 // transform relu(x*scale+shift)); bias [64] or NULL; stats_partial (optional) [n_partials][64][2].
 // Call with out == NULL to query *n_partials.
-extern "C" int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
+template <bool XFORM, bool BWD, int TAPS>
+static int tconv2_launch(const T2Params &p, int blocks, size_t lds, const float *x, const float *scale,
+                         const float *shift, const float *Wp, const float *bias, float *out, float *stats_partial,
+                         const float *bwd_z, const float *bwd_fin, void *stream) {
+  auto kern = tconv2_kernel<53, XFORM, BWD, TAPS>;
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(kern, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
+                     stats_partial, bwd_z, bwd_fin);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+extern "C" int p2r_stgcn_tconv2_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
                                         const float *Wp, const float *bias, float *out, float *stats_partial,
                                         int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream) {
-  if (N < 0 || T <= 0 || V != 53 || (scale == nullptr) != (shift == nullptr)) return P2R_EINVAL;
+  if (N < 0 || T <= 0 || V != 53 || (taps != 1 && taps != 3) || (scale == nullptr) != (shift == nullptr)) return P2R_EINVAL;
   if ((bwd_z == nullptr) != (bwd_fin == nullptr) || (bwd_z && (scale || !stats_partial))) return P2R_EINVAL;
   if (n_partials) *n_partials = 0;
   if (N == 0) return P2R_OK;
@@ -450,28 +469,10 @@ extern "C" int p2r_stgcn_tconv2_forward(int N, int T, int V, const float *x, con
   const size_t lds = (size_t)2 * (T2_CP * T2_F * V + T2_CP * 2 * V) * sizeof(float) + (size_t)T2_NW * 128 * sizeof(float) +
                      (size_t)(128 + 64 + 128) * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
-  if (bwd_z) {
-    auto kern = tconv2_kernel<53, false, true>;
-    static unsigned char lds_ok[P2R_MAX_DEVICES];
-    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                       stats_partial, bwd_z, bwd_fin);
-  } else if (scale) {
-    auto kern = tconv2_kernel<53, true, false>;
-    static unsigned char lds_ok[P2R_MAX_DEVICES];
-    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                       stats_partial, nullptr, nullptr);
-  } else {
-    auto kern = tconv2_kernel<53, false, false>;
-    static unsigned char lds_ok[P2R_MAX_DEVICES];
-    hipError_t e = p2r_allow_big_lds(kern, lds_ok);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T2_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                       stats_partial, nullptr, nullptr);
-  }
-  P2R_LAUNCH_CHECK();
-  return P2R_OK;
+#define P2R_T2(XF, BW) (taps == 3 ? tconv2_launch<XF, BW, 3>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream) \
+                                   : tconv2_launch<XF, BW, 1>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream))
+  if (bwd_z) return P2R_T2(false, true);
+  if (scale) return P2R_T2(true, false);
+  return P2R_T2(false, false);
+#undef P2R_T2
 }

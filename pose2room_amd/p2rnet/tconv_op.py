@@ -29,7 +29,7 @@ def _permute_taps(W3):
 
 
 def _tconv2_able(W3, V):
-    return W3.shape[0] == 3 and V == 53
+    return W3.shape[0] in (1, 3) and V == 53
 
 
 def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
@@ -48,7 +48,7 @@ def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
             st = _lib.current_stream(x.device)
             if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
                 part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
-            _lib.check(lib.p2r_stgcn_tconv2_forward(N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
+            _lib.check(lib.p2r_stgcn_tconv2_forward(N, T, V, Wp.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
                                                     _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None,
                                                     _lib.ptr(bz), _lib.ptr(bfin), st),
                        "stgcn_tconv2_forward")
