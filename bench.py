@@ -347,7 +347,7 @@ def main():
         sps = world * args.batch * args.steps / elapsed
         tflops = sps * gflop_per_sample(args.frames) / 1e3
         line = {
-            'metric': 'P2RNet train-step samples/sec (T=1024,J=53,bs=32)', 'value': round(sps, 3),
+            'metric': f'P2RNet train-step samples/sec (T={args.frames},J=53,bs={args.batch})', 'value': round(sps, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'step_ms': step_ms,
@@ -357,7 +357,8 @@ def main():
                     'how': 'batch copied from pinned host memory every step (reference to_device), one step ahead on a '
                            'side stream'},
             'config': {'workload': f'P2RNet full train step, bs={args.batch}/GPU, T={args.frames}, J=53, '
-                                   f'seeds=512, proposals=128 (BASELINE configs[2])',
+                                   f'seeds=512, proposals=128'
+                                   + (' (BASELINE configs[2])' if (args.batch, args.frames) == (32, 1024) else ''),
                        'input': 'P2RNet_dataloader over SyntheticPoseDataset' + (' + DistributedSampler' if world > 1 else ''),
                        'global_batch': world * args.batch, 'frames': args.frames,
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
