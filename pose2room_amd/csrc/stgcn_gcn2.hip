@@ -382,11 +382,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
         constexpr int R4 = RS / 4;                          // float4 per row (212)
         constexpr int RIT = (R4 + 63) / 64;                 // 4
         float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
+        float4 ad[BWD ? 2 : 1][BWD ? RIT : 1];
         unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
-        if (BWD) {   // saved activation + mask bytes of this wave's two rows: in flight across the staging barrier
+        if (BWD) {   // saved activation, mask bytes and addend of this wave's two rows: in flight across the staging barrier
           const size_t r0 = (size_t)(16 * m + 2 * wave) * row_stride;
           const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
           const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
+          const float4 *a4 = reinterpret_cast<const float4 *>(ag ? ag + r0 : nullptr);
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
               const int c4 = it * 64 + lane;
               uv[rr][it] = c4 < R4 ? u4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
               mk[rr][it] = c4 < R4 ? m4[(size_t)rr * (row_stride / 4) + c4] : 0u;
+              if (a4 && c4 < R4) ad[rr][it] = a4[(size_t)rr * (row_stride / 4) + c4];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -402,16 +405,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
         const float4 *arow = reinterpret_cast<const float4 *>(ag ? ag + (size_t)16 * m * row_stride : nullptr);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
         if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
-          float4 ad[2][RIT];
-          if (arow) {
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-              for (int it = 0; it < RIT; ++it) {
-                const int c4 = it * 64 + lane;
-                if (c4 < R4) ad[rr][it] = arow[(size_t)(2 * wave + rr) * (row_stride / 4) + c4];
-              }
-          }
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * wave + rr, c = 16 * m + row;
