@@ -311,7 +311,7 @@ int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const float *x, const
                             const float *shift, const float *W, const float *bias,
                             float *out, float *stats_partial, int *n_partials, void *stream);
 
-/* weight gradient: dw_partial [n_blocks][taps][64][64] (summed by the caller) of
+/* weight gradient: dw_partial [n_blocks][64 c][64 ci][taps] (the layout of the Conv2d weight; summed by the caller) of
  * sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-(taps-1)/2,w] with h as above; dbias_partial,
  * when not NULL, [n_blocks][64] = per-workgroup sums of dout per channel (bias gradient). */
 int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,

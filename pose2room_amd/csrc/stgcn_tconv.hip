@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       if (lane == 0) dbias_partial[(size_t)blockIdx.x * TC_C + wave + hh * (TW_THREADS / 64)] = v;
     }
   }
-  // partial[block][p][c][ci]: D[row = 4g + q][col = r] -> c = 16*TW_MT*mh + 16*m + row, ci = 16*nt + r
+  // partial[block][c][ci][p] (the layout of Conv2d.weight (c, ci, taps, 1)): D[row = 4g + q][col = r] -> c = 16*TW_MT*mh + 16*m + row, ci = 16*nt + r
   float *outp = dw_partial + (size_t)blockIdx.x * TAPS * TC_C * TC_C;
 #pragma unroll
   for (int p = 0; p < TAPS; ++p)
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
     for (int m = 0; m < TW_MT; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        outp[((size_t)p * TC_C + 16 * TW_MT * mh + 16 * m + 4 * g + q) * TC_C + 16 * nt + r] = acc[p][m][q];
+        outp[((size_t)(16 * TW_MT * mh + 16 * m + 4 * g + q) * TC_C + 16 * nt + r) * TAPS + p] = acc[p][m][q];
 }
 
 }  // namespace
@@ -420,7 +420,7 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   return P2R_OK;
 }
 
-// dw_partial [n_blocks][taps][64][64] and (optional) dbias_partial [n_blocks][64] = row sums of dout,
+// dw_partial [n_blocks][64 c][64 ci][taps] and (optional) dbias_partial [n_blocks][64] = row sums of dout,
 // both summed over the leading axis by the caller.
 extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, const float *scale,
                                            const float *shift, const float *dout, int n_blocks,

@@ -142,15 +142,14 @@ class _BNReLUTConv(Function):
                                             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
                        "bn_bwd_apply")
             taps = ctx.taps
-            part = torch.empty((_N_BLOCKS, taps, 64, 64), dtype=torch.float32, device=dev)
+            part = torch.empty((_N_BLOCKS, 64, 64, taps), dtype=torch.float32, device=dev)
             bpart = torch.empty((_N_BLOCKS, 64), dtype=torch.float32, device=dev) if ctx.has_bias else None
             _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
                                                        _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
                        "stgcn_tconv_weight_grad")
-            # flattened first: a size-1 tap axis would otherwise keep the permuted stride, which DDP's bucket views reject
-            dW = part.sum(0).permute(1, 2, 0).reshape(-1).view(ctx.wshape)
+            dW = part.sum(0).view(ctx.wshape)      # the kernel writes its partials in the weight's own (c, ci, tap) order
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
-                dbias = bpart.double().sum(0).float()
+                dbias = bpart.sum(0)
         return dz, dgamma, dbeta, None, dW, dbias, None, None, None, None
 
 
