@@ -93,11 +93,13 @@ class BNLink(object):
     input and identity branch), that op's data-gradient kernel produces the whole gradient of y, so it can also
     emit the two per-channel sums of this BatchNorm's backward from its row epilogue (`partials`), which replaces
     the reduction pass over the gradient and the saved input.  `grad_ptr` identifies the gradient buffer the
-    sums belong to; the BatchNorm backward uses them only for that very buffer."""
-    __slots__ = ('u', 'mask', 'fin', 'partials', 'grad_ptr', 'used')
+    sums belong to and `grad_version` its version counter when the kernel wrote it; the BatchNorm backward uses
+    the sums only for that very buffer in that very state (a second consumer of y would make autograd hand over a
+    different tensor, or accumulate into this one in place, which bumps the counter)."""
+    __slots__ = ('u', 'mask', 'fin', 'partials', 'grad_ptr', 'grad_version', 'used')
 
     def __init__(self):
-        self.u = self.mask = self.fin = self.partials = self.grad_ptr = None
+        self.u = self.mask = self.fin = self.partials = self.grad_ptr = self.grad_version = None
         self.used = 0           # how many backward passes took the sums from the link (tests)
 
 
@@ -129,10 +131,11 @@ class _FusedBNAct(Function):
         lib = _lib.lib()
         link, part = ctx.link, None
         if link is not None:
-            if link.partials is not None and link.grad_ptr == dy.data_ptr():
+            if (link.partials is not None and link.grad_ptr == dy.data_ptr()
+                    and link.grad_version == dy._version):
                 part = link.partials        # emitted by the kernel that wrote dy (gcn_op._GraphConv.backward)
                 link.used += 1
-            link.partials = link.grad_ptr = None
+            link.partials = link.grad_ptr = link.grad_version = None
         if part is None:
             part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):

@@ -141,7 +141,7 @@ class _GraphConv(Function):
                     # dx is the whole gradient of the previous block's output: its BatchNorm backward takes the
                     # two per-channel sums from here instead of a pass over dx and its saved input
                     dx, link.partials = dx
-                    link.grad_ptr = dx.data_ptr()
+                    link.grad_ptr, link.grad_version = dx.data_ptr(), dx._version
                 dres = None
             else:
                 Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]

@@ -120,11 +120,14 @@ def test_adjacency_gradient_reaches_zero_valued_entries(dev):
     assert (ib.grad[zeroed & (At != 0)].abs() > 1e-3 * scale).any()      # those gradients are not trivially zero
 
 
-@pytest.mark.parametrize("N,T", [(2, 40), (3, 130), (1, 7)])
-def test_chained_blocks_bn_backward_from_the_data_gradient_epilogue(dev, N, T):
+@pytest.mark.parametrize("N,T,tap", [(2, 40, False), (3, 130, False), (1, 7, False), (2, 40, True)])
+def test_chained_blocks_bn_backward_from_the_data_gradient_epilogue(dev, N, T, tap):
     """Two chained st_gcn_blocks: with `chain_input` the second block's graph-conv data-gradient kernel emits the
     reduction sums of the first block's BatchNorm + residual + ReLU backward (bn_op.BNLink).  Gradients must equal
-    those of the separate reduction pass, and the link must actually have been used."""
+    those of the separate reduction pass, and the link must actually have been used.
+    tap: the first block's output ALSO feeds the loss directly although `chain_input` claims a single consumer;
+    the gradient reaching its BatchNorm is then not the buffer the kernel wrote, the link must notice and the
+    gradients must still be right."""
     import copy
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph, st_gcn_block
     from pose2room_amd.p2rnet import gcn_op
@@ -144,17 +147,26 @@ def test_chained_blocks_bn_backward_from_the_data_gradient_epilogue(dev, N, T):
     def run(net, chain):
         x = x0.clone().requires_grad_(True)
         h = x + 0.0                       # a non-leaf input, as in the model
+        mid = None
         for i, b in enumerate(net):
             b.chain_input = chain and i > 0
             h, _ = b(h, A)
+            if i == 0:
+                mid = h
             if chain and hasattr(h, '_p2r_bn_link'):
                 links.append(h._p2r_bn_link)
-        (h * w).sum().backward()
+        loss = (h * w).sum()
+        if tap:
+            loss = loss + (mid * w.flip(0)).sum()
+        loss.backward()
         return x.grad, {k: p.grad for k, p in net.named_parameters()}
 
     gx_a, gp_a = run(blocks, True)
     gx_b, gp_b = run(ref, False)
-    assert links and links[0].used == 1, "the BatchNorm backward did not take its sums from the link"
+    if tap:
+        assert links and links[0].used == 0, "the link was used although the gradient had a second contribution"
+    else:
+        assert links and links[0].used == 1, "the BatchNorm backward did not take its sums from the link"
 
     def close(a, b, name):
         scale = max(b.abs().max().item(), 1.0)
