@@ -307,16 +307,36 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int b, int G, int S, int
   }
 }
 
+// The workgroups of fps_coop_kernel wait for each other, so all of them must be resident at once.  A plain launch only
+// ASSUMES that (b*G <= compute units); a kernel of another stream or process holding compute units breaks it.  The
+// launch therefore goes through hipLaunchCooperativeKernel, which places the grid as a whole or refuses it
+// (hipErrorCooperativeLaunchTooLarge: the caller then takes the one-workgroup-per-cloud kernel).  The bounded spin in
+// the kernel stays as the last line of defence: a peer that never shows up ends the launch with -1 picks, which the
+// Python binding turns into a RuntimeError (pointnet2_ops/_ext.py).  Returns P2R_OK, 1 = "not placed, use the
+// fallback", or an error code.
 template <int PPT>
 int launch_coop(int b, int G, int S, int n, int m, int L, const float *dataset, float *temp, int *idxs,
                 hipStream_t st) {
   const size_t slot_bytes = (size_t)b * 4 * G * sizeof(unsigned long long);
+  int dev = 0, coop = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_kernel<PPT>, 1024, 0) != hipSuccess || per_cu < 1)
+    return 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || b * G > cus) return 1;
   {
     hipError_t e = hipMemsetAsync(temp, 0, slot_bytes, st);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((fps_coop_kernel<PPT>), dim3(b * G), dim3(1024), 0, st, b, G, S, n, m, L, dataset,
-                     reinterpret_cast<unsigned long long *>(temp), idxs);
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(temp);
+  void *args[] = {&b, &G, &S, &n, &m, &L, &dataset, &slots, &idxs};
+  hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fps_coop_kernel<PPT>), dim3(b * G),
+                                            dim3(1024), args, 0, st);
+  if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  if (e != hipSuccess) return (int)e;
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -373,11 +393,13 @@ extern "C" int p2r_furthest_point_sampling(int b, int n, int m, const float *dat
   const int S = (n + G - 1) / G;
   if (G >= 2 && S <= 16384 && (reinterpret_cast<uintptr_t>(temp) & 7) == 0 &&
       (size_t)b * 4 * G * sizeof(unsigned long long) <= (size_t)b * n * sizeof(float)) {
-    if (S <= 1024) return launch_coop<1>(b, G, S, n, m, L, dataset, temp, idxs, st);
-    if (S <= 2048) return launch_coop<2>(b, G, S, n, m, L, dataset, temp, idxs, st);
-    if (S <= 4096) return launch_coop<4>(b, G, S, n, m, L, dataset, temp, idxs, st);
-    if (S <= 8192) return launch_coop<8>(b, G, S, n, m, L, dataset, temp, idxs, st);
-    return launch_coop<16>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    int rc;
+    if (S <= 1024) rc = launch_coop<1>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    else if (S <= 2048) rc = launch_coop<2>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    else if (S <= 4096) rc = launch_coop<4>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    else if (S <= 8192) rc = launch_coop<8>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    else rc = launch_coop<16>(b, G, S, n, m, L, dataset, temp, idxs, st);
+    if (rc != 1) return rc;      // placed (or a real error); 1: co-residency not guaranteed -> one workgroup per cloud
   }
   hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, L, dataset, temp, idxs);
   P2R_LAUNCH_CHECK();

@@ -569,7 +569,10 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
   const long long tiles = (long long)N * p.tiles_per_seq;
   if (tiles > 0x7fffffffLL) return P2R_EINVAL;
   p.total_tiles = (int)tiles;
-  p.vec = (((size_t)T * V) % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;
+  // one predicate for the 16-byte DMA pieces of x AND the 16-byte row stores / loads of the staged epilogue: z, the
+  // addend (a contiguous view may start anywhere) and the saved activation of the BWD epilogue must be aligned too
+  p.vec = (((size_t)T * V) % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)z % 16) == 0 &&
+           ((uintptr_t)addend % 16) == 0) ? 1 : 0;
   const int blocks = (int)(tiles < 256 ? tiles : 256);
   if (n_partials) *n_partials = blocks;
   if (!z) return P2R_OK;

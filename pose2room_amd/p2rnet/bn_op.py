@@ -96,11 +96,25 @@ class BNLink(object):
     sums belong to and `grad_version` its version counter when the kernel wrote it; the BatchNorm backward uses
     the sums only for that very buffer in that very state (a second consumer of y would make autograd hand over a
     different tensor, or accumulate into this one in place, which bumps the counter)."""
-    __slots__ = ('u', 'mask', 'fin', 'partials', 'grad_ptr', 'grad_version', 'used')
+    __slots__ = ('u', 'mask', 'fin', 'versions', 'partials', 'grad_ptr', 'grad_version', 'used')
 
     def __init__(self):
-        self.u = self.mask = self.fin = self.partials = self.grad_ptr = self.grad_version = None
+        self.u = self.mask = self.fin = self.versions = self.partials = self.grad_ptr = self.grad_version = None
         self.used = 0           # how many backward passes took the sums from the link (tests)
+
+    def attach(self, u, mask, fin):
+        """The BatchNorm's saved input, ReLU mask bytes and constants.  They are plain references (the consumer is
+        another autograd Function, so they cannot ride in ITS saved tensors): the version counters recorded here
+        stand in for autograd's saved-tensor check."""
+        self.u, self.mask, self.fin = u, mask, fin
+        self.versions = (u._version, mask._version, fin._version)
+
+    def intact(self):
+        """False when u / mask / fin were modified in place after the forward: the sums would be computed from other
+        values than the BatchNorm backward itself reads, so the consumer must not emit them (the BatchNorm then runs
+        its own reduction pass, and autograd's own check on ITS saved tensors raises as for any in-place change)."""
+        return (self.u is not None and self.versions is not None and
+                self.versions == (self.u._version, self.mask._version, self.fin._version))
 
 
 class _FusedBNAct(Function):
@@ -117,7 +131,7 @@ class _FusedBNAct(Function):
         ctx.has_res = res is not None
         ctx.link = link if relu else None
         if ctx.link is not None:
-            link.u, link.mask, link.fin = x, mask, fin
+            link.attach(x, mask, fin)
         return y
 
     @staticmethod

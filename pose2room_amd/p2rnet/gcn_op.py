@@ -30,17 +30,31 @@ class GraphTables:
         self.nbr_r, self.gidx_r, self.Lk_r = gcn_tables.build(A, transpose=True)
         self.LkA_c = (ctypes.c_int * self.K)(*self.Lk_c)
         self.LkA_r = (ctypes.c_int * self.K)(*self.Lk_r)
-        # static work schedules of the second-generation kernels (unit = (plane, joint) with a non-empty list)
-        self.stream_c = torch.from_numpy(gcn_tables.build_stream(self.nbr_c, self.gidx_c, self.Lk_c)[0])
-        self.stream_r = torch.from_numpy(gcn_tables.build_stream(self.nbr_r, self.gidx_r, self.Lk_r)[0])
+        # static work schedules of the second-generation kernels (unit = (plane, joint) with a non-empty list).  They
+        # exist for the P2RNet skeleton size only (csrc/stgcn_gcn2.hip is a V = 53 kernel) and only when the pattern
+        # fits the kernel's record budget; any other adjacency runs on the first-generation kernels.
+        self.stream_c = self.stream_r = None
+        if self.V == 53 and self.K < 15:
+            try:
+                sc = gcn_tables.build_stream(self.nbr_c, self.gidx_c, self.Lk_c)[0]
+                sr = gcn_tables.build_stream(self.nbr_r, self.gidx_r, self.Lk_r)[0]
+                self.stream_c, self.stream_r = torch.from_numpy(sc), torch.from_numpy(sr)
+            except gcn_tables.StreamBudgetError:
+                pass
         self._dev = {}
+
+    @property
+    def gen2(self):
+        """True when the second-generation kernels (static work streams) serve this adjacency pattern."""
+        return self.stream_c is not None
 
     def on(self, device):
         key = str(device)
         if key not in self._dev:
             self._dev[key] = dict(nbr_c=self.nbr_c.to(device), gidx_c=self.gidx_c.to(device),
                                   nbr_r=self.nbr_r.to(device), gidx_r=self.gidx_r.to(device),
-                                  stream_c=self.stream_c.to(device), stream_r=self.stream_r.to(device),
+                                  stream_c=self.stream_c.to(device) if self.gen2 else None,
+                                  stream_r=self.stream_r.to(device) if self.gen2 else None,
                                   # 1 for a real list slot, 0 for padding (the adjacency gradient must also reach
                                   # real entries whose current coefficient happens to be zero)
                                   real_r=(self.gidx_r >= 0).to(torch.float32).to(device).contiguous())
@@ -98,7 +112,7 @@ class _GraphConv(Function):
         t = tables.on(dev)
         x = x.contiguous()
         W = weight.contiguous()
-        if tables.V == 53:      # second-generation kernel (csrc/stgcn_gcn2.hip)
+        if tables.gen2:         # second-generation kernel (csrc/stgcn_gcn2.hip)
             out = _gcn2_forward(x, wp_f if wp_f is not None else permute_planes(W.view(tables.K, 64, 64)),
                                 coef_c.contiguous(), t['stream_c'], bias_cv.contiguous(), tables, want_stats)
         else:
@@ -130,9 +144,9 @@ class _GraphConv(Function):
         dx = dW = dcoef_r = dbias = None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
-            if tables.V == 53:
+            if tables.gen2:
                 link = ctx.bn_link
-                use_link = link is not None and link.u is not None and link.u.shape == x.shape
+                use_link = link is not None and link.intact() and link.u.shape == x.shape
                 wp_b = ctx.wp_b if ctx.wp_b is not None else permute_planes(W.view(K, C, C).transpose(1, 2))
                 dx = _gcn2_forward(dz, wp_b, coef_r.contiguous(),
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,

@@ -50,6 +50,10 @@ def coefficients(Aeff, gidx):
 STREAM_UMAX, STREAM_REC, STREAM_HDR = 80, 12, 16     # csrc/stgcn_gcn2.hip: G2_UMAX, G2_REC, G2_HDR
 
 
+class StreamBudgetError(ValueError):
+    """The adjacency pattern does not fit the static work stream of the second-generation kernels."""
+
+
 def deal_runs(cost, n_waves, slots):
     """Joints -> (wave, slot) such that a wave's slots 0-3 hold one run of CONSECUTIVE joints and its slots 4-6 a
     second one (the kernel stores the values of a run with one 16- or 12-byte store per lane).
@@ -60,7 +64,8 @@ def deal_runs(cost, n_waves, slots):
     lightest busiest wave.  Returns per wave the list of 7 slot joints (-1 = unused slot)."""
     import itertools
     V = len(cost)
-    assert n_waves == 8 and slots == 7 and 3 * 16 <= V <= 4 * 8 + 3 * 8
+    if not (n_waves == 8 and slots == 7 and 3 * 16 <= V <= 4 * 8 + 3 * 8):
+        raise StreamBudgetError('joint count %d outside 48..56' % V)
     n4 = V - 3 * 16                                   # runs of four (the other 16 - n4 runs have three joints)
     best = None
     for pos in itertools.combinations(range(16), n4):
@@ -112,7 +117,8 @@ def build_stream(nbr, gidx, Lk, n_waves=8, slots=7, joint_stride=1):
     nbr = np.asarray(nbr)
     V = gidx.shape[1]
     K = len(Lk)
-    assert K < 15 and slots <= 7 and V * joint_stride * 4 < 65536
+    if not (K < 15 and slots <= 7 and V * joint_stride * 4 < 65536):
+        raise StreamBudgetError('K = %d, V = %d' % (K, V))
     lofs = np.concatenate([[0], np.cumsum(Lk)])
     length = np.zeros((K, V), dtype=np.int64)           # real list length per (plane, joint)
     for k in range(K):
@@ -147,7 +153,8 @@ def build_stream(nbr, gidx, Lk, n_waves=8, slots=7, joint_stride=1):
                         recs.append((k, slot, first, chunks[slot][pass_i]))
                         first = False
                 visits += 1
-        assert len(recs) + 2 <= STREAM_UMAX, len(recs)
+        if len(recs) + 2 > STREAM_UMAX:
+            raise StreamBudgetError('%d records for one wave (budget %d)' % (len(recs), STREAM_UMAX - 2))
         for u, (k, slot, first, ch) in enumerate(recs):
             later = [kk for (kk, _, f, _) in recs[u + 1:] if f]
             nk = later[0] if later else 15

@@ -129,7 +129,7 @@ class BoxNetDetectionLoss(BaseLoss):
 
     # loss.py:152-189
     def __call__(self, est_data, gt_data, dataset_config):
-        if est_data['vote_xyz'].is_cuda:
+        if fused_supported(est_data, gt_data):
             return fused_detection_loss(est_data, gt_data, self.origin_joint_id)
         return self.composed(est_data, gt_data, dataset_config)
 
@@ -153,6 +153,35 @@ class BoxNetDetectionLoss(BaseLoss):
                 'center_loss': center_loss, 'size_loss': size_loss, 'heading_loss': heading_loss,
                 'sem_cls_loss': sem_cls_loss, 'pos_ratio': pos_ratio, 'neg_ratio': neg_ratio,
                 'obj_acc': obj_acc}
+
+
+_F32_EST = ('vote_xyz', 'objectness_scores', 'center', 'size', 'sem_cls_scores', 'seed_skeleton',
+            'aggregated_vote_xyz')
+_F32_GT = ('vote_label', 'center_label', 'box_label_mask', 'size', 'heading')
+_MAX_GT, _DL_T, _DL_NPART = 32, 256, 12        # csrc/det_loss.hip: DL_MAXG, DL_T, DL_NPART
+
+
+def fused_supported(est_data, gt_data):
+    """True when the fused op (csrc/det_loss.hip) takes these tensors as they are: everything on one GPU, the dtypes
+    the kernel reads through raw pointers (f32 everywhere except the f64 heading head and the int64 masks / labels /
+    seed indices' integer type), at most 32 ground-truth slots and a per-sample working set inside its 64 KB of LDS.
+    Anything else (autocast outputs, a loader emitting float64 boxes, more ground-truth slots) takes `composed`."""
+    v = est_data['vote_xyz']
+    if not v.is_cuda:
+        return False
+    dev = v.device
+    for d, names, dt in ((est_data, _F32_EST, torch.float32), (gt_data, _F32_GT, torch.float32),
+                         (est_data, ('heading',), torch.float64),
+                         (gt_data, ('vote_label_mask', 'sem_cls_label'), torch.int64)):
+        for n in names:
+            t = d[n]
+            if not torch.is_tensor(t) or t.dtype != dt or t.device != dev:
+                return False
+    if est_data['seed_inds'].device != dev or est_data['seed_inds'].dtype not in (torch.int32, torch.int64):
+        return False
+    G, K = gt_data['center_label'].shape[1], est_data['center'].shape[1]
+    lds = _DL_T * _DL_NPART * 4 + _DL_T * 8 + G * K * 4 + 4 * G * 4 + G * 4 + 3 * K * 4
+    return 0 < G <= _MAX_GT and lds <= 64 * 1024
 
 
 _NAMES32 = ('vote_loss', 'objectness_loss', 'center_loss', 'size_loss', 'sem_cls_loss', 'pos_ratio', 'neg_ratio',

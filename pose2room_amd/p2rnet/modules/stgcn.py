@@ -130,7 +130,7 @@ class STGCN(nn.Module):
         x = self.embed(input_joints)
         blocks = self.st_gcn_networks
         tables = blocks[0].gcn.tables
-        if tables is not None and tables.V == 53 and all(b.chainable(x, self.A) for b in blocks):
+        if tables is not None and tables.gen2 and all(b.chainable(x, self.A) for b in blocks):
             # fused train-mode path: the per-block parameter transforms are computed for all blocks at once
             from ..gcn_op import prepare_chain
             for gcn, prep in zip(blocks, prepare_chain(blocks, self.A, self.edge_importance, tables)):

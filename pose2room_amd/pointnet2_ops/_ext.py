@@ -47,6 +47,9 @@ def _stream(t):
     return _lib.current_stream(t.device)
 
 
+_FPS_COOP_MIN_N = 16384      # csrc/fps.hip: largest cloud one workgroup holds in registers
+
+
 def furthest_point_sampling(points, nsamples):
     """points (B,N,3) f32 -> (B,nsamples) i32.  sampling.cpp:66-87."""
     _check(points, "points", torch.float32)
@@ -62,6 +65,14 @@ def furthest_point_sampling(points, nsamples):
         _lib.check(_lib.lib().p2r_furthest_point_sampling(
             _c_int(b), _c_int(n), _c_int(nsamples), _lib.ptr(points), _lib.ptr(tmp),
             _lib.ptr(output), _stream(points)), "furthest_point_sampling")
+    if n > _FPS_COOP_MIN_N and b > 0 and nsamples > 0:
+        # clouds beyond one workgroup's registers may run on several co-operating workgroups (csrc/fps.hip).  Should
+        # a peer workgroup not show up within the kernel's spin bound the remaining picks come back as -1; surface
+        # that here instead of letting gather_points read out of bounds.  (One sync, on this path only; the P2RNet
+        # clouds of 512 points never take it.)
+        if bool((output[:, -1] < 0).any()):
+            raise RuntimeError("furthest_point_sampling: co-operating workgroups lost each other (device shared "
+                               "with another stream / process?); no valid sample indices were produced")
     return output
 
 

@@ -48,3 +48,21 @@ def test_fused_bn_act(dev, shape, with_res, train):
         torch.testing.assert_close(bn_new.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(bn_new.running_var, bn_ref.running_var, rtol=1e-5, atol=1e-6)
         assert int(bn_new.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+def test_bn_link_notices_in_place_modification(dev):
+    """The BNLink tensors are plain references outside autograd's saved-tensor check: the link records their version
+    counters and reports itself broken after an in-place change, so the graph-conv backward does not emit BatchNorm
+    sums from other values than the BatchNorm backward reads (advisor finding, round 2)."""
+    from pose2room_amd.p2rnet import bn_op
+    bn = torch.nn.BatchNorm2d(64).to(dev).train()
+    x = torch.randn(2, 64, 9, 53, device=dev, requires_grad=True)
+    link = bn_op.BNLink()
+    y = bn_op.fused_bn_act(x * 1.0, bn, None, relu=True, link=link)
+    assert y._p2r_bn_link is link and link.intact()
+    link.mask.bitwise_not_()                    # e.g. a stray in-place op on the saved mask bytes
+    assert not link.intact()
+    fresh = bn_op.BNLink()
+    assert not fresh.intact()                   # nothing attached yet
+    with pytest.raises(RuntimeError):           # autograd's own check on the BatchNorm's saved tensors still fires
+        y.sum().backward()

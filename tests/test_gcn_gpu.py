@@ -52,6 +52,48 @@ def test_graph_conv_forward_backward(dev, N, T):
     assert (idv.grad.cpu()[At == 0] == 0).all()
 
 
+def _ring_adjacency(K, V, seed):
+    """K planes over a V-joint ring skeleton: plane k links joints k hops apart (plus random extra links)."""
+    rng = np.random.RandomState(seed)
+    A = np.zeros((K, V, V), dtype=np.float32)
+    for k in range(K):
+        for v in range(V):
+            A[k, v, (v + k) % V] = rng.uniform(0.2, 1.0)
+            if rng.rand() < 0.3:
+                A[k, v, rng.randint(V)] = rng.uniform(0.2, 1.0)
+    return A
+
+
+@pytest.mark.parametrize("V", [25, 17, 64])
+def test_graph_conv_other_skeletons(dev, V):
+    """Joint counts other than the P2RNet skeleton's 53 have no static work stream: GraphTables builds without one
+    and the op runs on the first-generation kernels (forward, all four gradients), against the fp64 formulation."""
+    from pose2room_amd.p2rnet import gcn_op
+    K = 11
+    A = _ring_adjacency(K, V, V)
+    tables = gcn_op.GraphTables(A)
+    assert not tables.gen2 and tables.on(dev)['stream_c'] is None
+    g = torch.Generator().manual_seed(V)
+    N, T = 2, 37
+    x = torch.randn(N, 64, T, V, generator=g)
+    w = torch.randn(K * 64, 64, generator=g) / 8
+    b = torch.randn(K * 64, generator=g) * 0.1
+    imp = 1 + 0.1 * torch.randn(K, V, V, generator=g)
+    At = torch.tensor(A)
+    go = torch.randn(N, 64, T, V, generator=g)
+    xr, wr, br, ir = (t.double().requires_grad_(True) for t in (x, w, b, imp))
+    _reference(xr, wr, br, At.double() * ir).backward(go.double())
+    zr = _reference(xr, wr, br, At.double() * ir)
+    xd, wd, bd, idv = (t.to(dev).requires_grad_(True) for t in (x, w, b, imp))
+    z = gcn_op.graph_conv(xd, wd, bd, At.to(dev) * idv, tables)
+    z.backward(go.to(dev))
+    for a, ref, what in ((z.detach(), zr.detach(), "z"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dW"),
+                         (bd.grad, br.grad, "db"), (idv.grad, ir.grad, "d importance")):
+        scale = ref.abs().max().item() + 1e-12
+        err = (a.double().cpu() - ref).abs().max().item()
+        assert err <= 5e-5 * scale, f"V={V} {what}: err {err:.3e} vs scale {scale:.3e}"
+
+
 def test_block_fused_matches_unfused(dev):
     """st_gcn_block with the fused graph conv vs the same block on the torch path."""
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph, st_gcn_block
@@ -226,3 +268,31 @@ def test_prepare_chain_equals_per_block_parameter_transforms(dev):
         if k.endswith('gcn.conv.bias') or k.endswith('tcn.2.bias'):     # zero in exact arithmetic (see above)
             continue
         close(gp_a[k], gp_b[k], k)
+
+
+def test_gcn2_misaligned_addend_and_output(dev):
+    """The 16-byte row path of the second-generation kernel needs x, z AND the addend 16-byte aligned; an addend that
+    is a contiguous view at an odd float offset must take the scalar path, not fault (advisor finding, round 2)."""
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    t = tables.on(dev)
+    g = torch.Generator().manual_seed(3)
+    N, T = 2, 32
+    x = torch.randn(N, 64, T, V, generator=g).to(dev)
+    W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
+    Aeff = torch.tensor(A, dtype=torch.float32).to(dev)
+    coef = gcn_op.gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    bias = torch.zeros(64, V, device=dev)
+    add_al = torch.randn(N, 64, T, V, generator=g).to(dev)
+    store = torch.zeros(add_al.numel() + 1, device=dev)
+    store[1:] = add_al.reshape(-1)
+    add_mis = store[1:].view_as(add_al)                   # contiguous, data_ptr % 16 == 4
+    assert add_mis.is_contiguous() and add_mis.data_ptr() % 16 != 0
+    wp = gcn_op.permute_planes(W)
+    z0 = gcn_op._gcn2_forward(x, wp, coef, t['stream_c'], bias, tables, addend=add_al)
+    z1 = gcn_op._gcn2_forward(x, wp, coef, t['stream_c'], bias, tables, addend=add_mis)
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)

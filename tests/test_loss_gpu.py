@@ -107,3 +107,30 @@ def test_fused_detection_loss_component_gradients(dev):
     a, b = run(True), run(False)
     for k in ('center', 'heading', 'size'):
         torch.testing.assert_close(a[k].grad, b[k].grad, rtol=2e-5, atol=1e-7)
+
+
+def test_fused_loss_dispatch_falls_back(dev):
+    """Inputs the fused kernel cannot read as they are (float64 ground-truth boxes, more than 32 ground-truth slots)
+    take the composed form instead of being misread or raising (advisor finding, round 2)."""
+    from pose2room_amd.p2rnet import P2RConfig, default_config
+    from pose2room_amd.p2rnet import loss as L
+    cfg = P2RConfig(default_config('train', data={'num_frames': 16}), device=dev)
+    loss_fn = L.BoxNetDetectionLoss(1, dev, cfg)
+    est, gt = _scene(2, 64, 32, 16, seed=5, case='near')
+    est = {k: v.to(dev) for k, v in est.items()}
+    gt = {k: v.to(dev) for k, v in gt.items()}
+    assert L.fused_supported(est, gt)
+    want = loss_fn.composed(est, gt, None)
+    gt64 = dict(gt, center_label=gt['center_label'].double())
+    assert not L.fused_supported(est, gt64)
+    got = loss_fn(est, gt64, None)                       # routed to `composed`
+    np.testing.assert_allclose(got['total'].item(), want['total'].item(), rtol=1e-6)
+    half = dict(est, center=est['center'].half())
+    assert not L.fused_supported(half, gt)
+    # 40 ground-truth slots (8 more than the kernel's table): composed form, same value as 10 slots + padding
+    pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], 30, *t.shape[2:], dtype=t.dtype, device=dev)], 1)
+    gt40 = dict(gt, **{k: pad(gt[k]) for k in ('center_label', 'box_label_mask', 'size', 'heading', 'sem_cls_label')})
+    assert not L.fused_supported(est, gt40)
+    got = loss_fn(est, gt40, None)
+    for k in ('vote_loss', 'objectness_loss', 'size_loss', 'heading_loss', 'sem_cls_loss'):
+        np.testing.assert_allclose(got[k].item(), want[k].item(), rtol=1e-5, err_msg=k)

@@ -275,3 +275,19 @@ def test_optimizer_groups_and_bn_momentum_schedule():
     for _ in range(4):          # the constructor applies epoch 0 and keeps last_epoch = -1, like the reference's
         sched.step()
     assert all(m.momentum == 0.25 for m in bns) and sched.last_epoch == 3
+
+
+def test_graph_tables_other_skeletons_cpu():
+    """GraphTables (and with it STGCN) can be built for any adjacency: the static work stream of the second-generation
+    kernels exists only for 53-joint patterns that fit its record budget (advisor finding, round 2)."""
+    import numpy as np
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    rng = np.random.RandomState(0)
+    t = gcn_op.GraphTables((rng.rand(3, 25, 25) > 0.8).astype(np.float32))
+    assert not t.gen2 and t.V == 25 and t.K == 3
+    dense = gcn_op.GraphTables(np.ones((11, 53, 53), dtype=np.float32))     # 53 joints, far over the record budget
+    assert not dense.gen2
+    assert gcn_op.GraphTables(Graph().A).gen2                                # the P2RNet skeleton keeps its stream
+    with pytest.raises(gcn_tables.StreamBudgetError):
+        gcn_tables.deal_runs([1] * 25, 8, 7)
