@@ -20,10 +20,14 @@ host memory each step, prefetched one step ahead on a side stream -- and reporte
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   step_ms      -- median / p10 / p90 of the per-step device time (events between steps, no host sync);
   h2d          -- the same run with the batch copied host -> device every step (pinned, prefetched);
-  roofline     -- the dominant kernel (gcn2_kernel) against the fp32 MFMA roof: algorithmic FLOPs
-                  per launch / event-timed launch duration, executed-MFMA fraction, HBM traffic from PMC;
-  step_roofline-- the whole step with the reference's algorithmic FLOPs (and the executed-MFMA share);
-  kernels      -- event-timed durations of the other HIP kernels at the P2RNet shapes;
+  verify       -- what was checked at the bench shape BEFORE timing (finite losses of a train step; sample 0 of the
+                  full batch against the same sample run alone with running-statistics BatchNorm);
+  roofline     -- the dominant kernel (gcn2_kernel) against the fp32 MFMA roof: MFMA FLOPs the kernel ISSUES per
+                  launch / its average duration INSIDE the step (HIP events around every launch of instrumented
+                  steps that follow the timed region); the dense-equivalent figure is a sub-key;
+  mfma_kernels -- the same for the other MFMA kernels of the ST-GCN blocks (in-step durations, issued FLOPs);
+  step_roofline-- the whole step: MFMA FLOPs issued per step (PMC profile) and the reference's algorithmic FLOPs;
+  kernels      -- event-timed durations of the pointnet2 / loss HIP kernels at the P2RNet shapes;
   cpu_baseline -- the same host model on the host cores with the CPU oracle behind
                   the ops ("port"), on a bounded sample.
 """
@@ -77,86 +81,167 @@ def _profile_json(name):
         return json.load(f)
 
 
-def dominant_kernel_roofline(device, batch, frames):
-    """The step's dominant kernel is gcn2_kernel (csrc/stgcn_gcn2.hip): 12 launches per step = 6 blocks x
-    (forward: column lists, bias table, statistics epilogue) + 6 x (data gradient: transposed planes, row
-    lists).  Both launch configurations are timed at the bench shape with events on the stream they are
-    launched on; `ms_per_launch` is their mean, which is what rocprofv3's per-kernel average over a bench
-    run shows.
+class LaunchTimer:
+    """HIP events around every call of the named C-ABI entry points (on the stream they launch on), to get a
+    kernel's duration INSIDE the train step -- with the caches, clocks and neighbours it has there -- rather than
+    in an isolated loop.  Used on extra steps after the timed region, never inside it."""
 
-    `flops_per_launch` is the ALGORITHMIC work of the operator in its sparse-adjacency form, the same figure
-    as in round 1: per frame a dense 64 x (11*64) x 53 product (4.78 MFLOP) plus the
-    971-non-zero graph product (0.12 MFLOP).  The kernel does less than that: a (plane, joint) unit whose
-    neighbour list is empty is skipped (454 of 583 units forward, 369 data gradient), so `executed` reports
-    the MFMA FLOPs actually issued and the matrix-pipe fraction they correspond to.  The reference's dense
-    formulation of the same op (conv1x1 to 704 channels + einsum) is `reference_algorithmic_tflops`."""
+    def __init__(self, lib, names):
+        self.lib, self.names, self.orig, self.records = lib, names, {}, []
+
+    def __enter__(self):
+        for name, tag_of in self.names.items():
+            orig = getattr(self.lib, name)
+            self.orig[name] = orig
+
+            def wrapper(*args, _orig=orig, _name=name, _tag_of=tag_of):
+                tag = _tag_of(args)
+                if tag is None:
+                    return _orig(*args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _orig(*args)
+                e1.record()
+                self.records.append((tag, e0, e1))
+                return rc
+            setattr(self.lib, name, wrapper)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self.orig.items():
+            setattr(self.lib, name, orig)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, e0, e1 in self.records:
+            out.setdefault(tag, []).append(e0.elapsed_time(e1))
+        return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+
+
+def _null(a):
+    return a is None or getattr(a, 'value', a) in (None, 0)
+
+
+# entry point -> tag of the launch (None: not timed).  Argument positions as in include/p2r_hip.h.
+_TIMED = {
+    'p2r_stgcn_gcn2_forward': lambda a: None if _null(a[12]) else ('gcn2_data_gradient' if _null(a[10]) else 'gcn2_forward'),
+    'p2r_stgcn_gcn_weight_grad': lambda a: None if _null(a[10]) else 'gcn_weight_grad',
+    'p2r_stgcn_gcn_coef_grad': lambda a: 'gcn_coef_grad',
+    'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv2_data_gradient' if _null(a[5]) else 'tconv2_forward'),
+    'p2r_stgcn_tconv_weight_grad': lambda a: 'tconv_weight_grad' if a[3] == 3 else None,
+}
+
+
+def issued_mfma_flops(batch, frames):
+    """MFMA FLOPs each ST-GCN kernel ISSUES per launch at this shape (v_mfma_f32_16x16x4_f32 = 2048 FLOP), counted
+    from the work tables the kernels run on -- units with an empty neighbour list are skipped, so this is less than
+    the dense operator (`dense_equivalent`, the figure of rounds 1-2).  Cross-checked against the
+    SQ_VALU_MFMA_BUSY_CYCLES x 64 of profiles/*_graphconv_mfma_util.json."""
+    import numpy as np
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     from pose2room_amd.p2rnet import gcn_op, gcn_tables
     A = Graph().A
     K, V = A.shape[0], A.shape[1]
     tables = gcn_op.GraphTables(A)
-    t = tables.on(device)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(batch, 64, frames, V, generator=g).to(device)
-    W = (torch.randn(K, 64, 64, generator=g) / 8).to(device)
-    Wp = gcn_op.permute_planes(W)
-    At = torch.tensor(A, dtype=torch.float32, device=device)
-    coef_c = gcn_tables.coefficients(At, t['gidx_c']).contiguous()
-    coef_r = gcn_tables.coefficients(At, t['gidx_r']).contiguous()
-    bias = torch.zeros(64, V, device=device)
-    configs = {
-        'forward': lambda: gcn_op._gcn2_forward(x, Wp, coef_c, t['stream_c'], bias, tables, True),
-        'data_gradient': lambda: gcn_op._gcn2_forward(x, Wp, coef_r, t['stream_r'], None, tables),
-    }
-    stream = torch.cuda.current_stream(device)
-    per = {}
-    for name, fn in configs.items():
-        for _ in range(3):
-            fn()
-        reps = 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
-            fn()
-        e1.record(stream)
-        e1.synchronize()
-        per[name] = e0.elapsed_time(e1) / reps
-    ms = sum(per.values()) / len(per)
+    hdr = gcn_tables.STREAM_UMAX * gcn_tables.STREAM_REC
+    tiles16 = batch * ((frames + 15) // 16)
+    per_rec = 4 * 16 * 2048.0                       # one record = 16 MFMAs in each of the 4 channel phases
+    out = {'gcn2_forward': int(tables.stream_c[:, hdr].sum()) * per_rec * tiles16,
+           'gcn2_data_gradient': int(tables.stream_r[:, hdr].sum()) * per_rec * tiles16}
+    out.update(gcn_op.grad_kernel_mfma_flops(tables, batch, frames))
+    out['tconv2_forward'] = out['tconv2_data_gradient'] = 3 * V * per_rec * tiles16
+    out['tconv_weight_grad'] = 3 * 2.0 * 64 * 64 * batch * frames * V
     cols = batch * frames * V
     nnz = int((A != 0).sum())
-    flops = (2.0 * 64 * 64 * K + 2.0 * 64 * nnz / V) * cols
-    ref_flops = (2.0 * 64 * 64 * K + 2.0 * 64 * V * K) * cols
-    # MFMA work actually issued: one record of the work stream = 16 MFMAs per channel phase = 4 * 16 * 2048 FLOP
-    # per 16-frame tile (lists longer than six entries take two records)
-    hdr = gcn_tables.STREAM_UMAX * gcn_tables.STREAM_REC
-    recs = {'forward': int(tables.stream_c[:, hdr].sum()), 'data_gradient': int(tables.stream_r[:, hdr].sum())}
-    tiles = batch * ((frames + 15) // 16)
-    exec_flops = sum(recs.values()) / 2.0 * tiles * 4 * 16 * 2048.0
-    tf = flops / ms / 1e9
-    traffic = _profile_json('r2_gcn2_pmc_traffic.json')
+    dense = (2.0 * 64 * 64 * K + 2.0 * 64 * nnz / V) * cols
+    ref = (2.0 * 64 * 64 * K + 2.0 * 64 * V * K) * cols
+    return out, dense, ref
+
+
+def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
+    """`steps` instrumented train steps -> per kernel: in-step average duration, issued MFMA FLOPs, fraction of the
+    fp32 MFMA peak.  Returns (roofline dict of the dominant kernel, table of the others)."""
+    from pose2room_amd import _lib
+    issued, dense, ref = issued_mfma_flops(batch_size, frames)
+    with LaunchTimer(_lib.lib(), _TIMED) as lt:
+        for _ in range(steps):
+            trainer.train_step(dict(batch))
+        per = lt.summary()
+
+    def row(tag):
+        ms, n = per[tag]
+        tf = issued[tag] / ms / 1e9
+        return {'ms_in_step': round(ms, 4), 'launches_per_step': n // steps, 'mfma_flops_issued': issued[tag],
+                'tflops': round(tf, 2), 'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+
+    rows = {tag: row(tag) for tag in sorted(per) if tag in issued}
+    g2 = [t for t in ('gcn2_forward', 'gcn2_data_gradient') if t in per]
+    n_g2 = sum(per[t][1] for t in g2)
+    ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
+    fl = sum(issued[t] * per[t][1] for t in g2) / n_g2
+    tf = fl / ms / 1e9
+    traffic = _profile_json('r3_gcn2_pmc_traffic.json') or _profile_json('r2_gcn2_pmc_traffic.json')
+    cols = batch_size * frames * 53
     scale = cols / float(32 * 1024 * 53)
-    return {'bound': 'mfma', 'kernel': 'gcn2_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
+    roof = {'bound': 'mfma', 'kernel': 'gcn2_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
             'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
             'traffic': int(traffic['bytes_per_launch'] * scale) if traffic else None,
-            'ms_per_launch': round(ms, 4), 'ms_forward': round(per['forward'], 4),
-            'ms_data_gradient': round(per['data_gradient'], 4), 'flops_per_launch': flops,
-            'executed': {'mfma_flops_per_launch': exec_flops, 'tflops': round(exec_flops / ms / 1e9, 2),
-                         'frac': round(exec_flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-                         'units': '454 of 583 (plane, joint) units forward, 369 data gradient'},
+            'ms_per_launch': round(ms, 4), 'timing': f'HIP events around each of the {n_g2 // steps} launches per step inside '
+                                                      f'{steps} instrumented train steps (includes the 2 us stream-fill pre-launch)',
+            'flops_per_launch': fl, 'flops': 'MFMA FLOPs issued (454 of 583 (plane, joint) units forward, 369 data gradient)',
+            'ms_forward': round(per['gcn2_forward'][0], 4) if 'gcn2_forward' in per else None,
+            'ms_data_gradient': round(per['gcn2_data_gradient'][0], 4) if 'gcn2_data_gradient' in per else None,
             'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
-            'reference_algorithmic_tflops': round(ref_flops / ms / 1e9, 2)}
+            'frac_dense_equivalent': round(dense / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'dense_equivalent': 'the operator with every (plane, joint) unit computed (the count rounds 1-2 quoted); '
+                                'the reference formulation (conv1x1 to 704 channels + dense einsum) would be '
+                                f'{round(ref / ms / 1e9, 1)} TFLOP/s'}
+    return roof, rows
 
 
-def step_executed_frac(ms_per_step, batch, frames):
-    """MFMA FLOPs the step's kernels actually issue (SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP/cycle/SIMD summed over one
-    step, profiles/r2_step_mfma.json from tools/pmc_step_mfma.sh at bs=32, T=1024; linear in batch * frames) over the
-    fp32 MFMA peak for the measured step time.  None when the profile is absent."""
-    prof = _profile_json('r2_step_mfma.json')
-    if not prof:
-        return None
-    flops = prof['mfma_busy_cycles_per_step'] * 64.0 * (batch * frames) / float(32 * 1024)
-    return round(flops / (ms_per_step * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+def step_mfma_issued(batch, frames):
+    """MFMA FLOPs the step's kernels issue (SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP/cycle/SIMD summed over one step, PMC
+    profile from tools/pmc_step_mfma.sh at bs=32, T=1024; linear in batch * frames).  (flops, source) or (None, None)."""
+    for name in ('r3_step_mfma.json', 'r2_step_mfma.json'):
+        prof = _profile_json(name)
+        if prof:
+            return prof['mfma_busy_cycles_per_step'] * 64.0 * (batch * frames) / float(32 * 1024), 'profiles/' + name
+    return None, None
+
+
+def verify_bench_shape(trainer, batch):
+    """Before anything is timed: (1) one train step at the bench shape gives finite losses; (2) with every BatchNorm
+    on its running statistics samples are independent, so sample 0 of the full batch must reproduce when it is run
+    alone -- this walks the persistent-workgroup kernels through tile counts far beyond one wave of workgroups and
+    catches batch- / tile-indexing faults that the small test shapes cannot.  Continuous tensors must agree to 1e-3
+    of their range (different GEMM tilings per batch size), the seed selection exactly; the proposal indices are
+    discrete functions of fp32 values (FPS over vote positions) and are REPORTED, not asserted."""
+    import math
+    out = trainer.train_step(dict(batch))
+    bad = [k for k, v in out.items() if not math.isfinite(float(v))]
+    assert not bad, f'non-finite losses at the bench shape: {bad}'
+    net = trainer.net.module
+    was_training = net.training
+    net.eval()
+    try:
+        with torch.no_grad():
+            full = net.generate_end_points(batch)
+            one = net.generate_end_points({k: (v[:1].contiguous() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    finally:
+        net.train(was_training)
+    assert torch.equal(full['seed_inds'][:1], one['seed_inds']), 'seed_inds of sample 0 differ between B and 1'
+    worst = 0.0
+    for k in ('seed_features', 'vote_xyz', 'vote_features'):
+        a, b = full[k][:1].float(), one[k].float()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), k
+        err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        assert err <= 1e-3, f'{k} of sample 0: batched vs alone differ by {err:.2e} of range'
+    same = torch.equal(full['aggregated_vote_inds'][:1], one['aggregated_vote_inds'])
+    return {'losses_finite': True, 'seed_inds_equal': True, 'max_rel_err_sample0': float(f'{worst:.2e}'),
+            'aggregated_vote_inds_equal': bool(same)}
 
 
 def kernel_microbench(device):
@@ -283,6 +368,7 @@ def main():
     def step():
         return trainer.train_step(dict(batch))
 
+    verify = verify_bench_shape(trainer, batch)      # not timed, not part of the warm-up count
     for _ in range(args.warmup):
         step()
     # Python's cyclic GC: the first full (generation-2) collection of a process walks every object torch and the
@@ -362,13 +448,20 @@ def main():
                        'input': 'P2RNet_dataloader over SyntheticPoseDataset' + (' + DistributedSampler' if world > 1 else ''),
                        'global_batch': world * args.batch, 'frames': args.frames,
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
-            'roofline': dominant_kernel_roofline(device, args.batch, args.frames),
-            'step_roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': FP32_MFMA_PEAK_TFLOPS * world,
-                              'unit': 'TFLOP/s', 'frac': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-                              'scope': 'whole train step: algorithmic fwd+bwd FLOPs of the REFERENCE step '
-                                       f'({gflop_per_sample(args.frames)} GFLOP/sample, dense graph product) / step time',
-                              'frac_executed': step_executed_frac(ms, args.batch, args.frames)},
+            'verify': verify,
         }
+        roof, rows = mfma_rooflines(trainer, batch, args.batch, args.frames)
+        line['roofline'] = roof
+        line['mfma_kernels'] = rows
+        issued, src = step_mfma_issued(args.batch, args.frames)
+        ex_tf = issued / (ms * 1e-3) / 1e12 if issued else None
+        line['step_roofline'] = {
+            'bound': 'mfma', 'achieved': round(ex_tf, 2) if issued else None, 'peak': FP32_MFMA_PEAK_TFLOPS * world,
+            'unit': 'TFLOP/s', 'frac': round(ex_tf / FP32_MFMA_PEAK_TFLOPS, 4) if issued else None,
+            'scope': f'whole train step of one rank: MFMA FLOPs issued per step ({src}) / step time',
+            'frac_reference_algorithmic': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            'reference_algorithmic': f'{gflop_per_sample(args.frames)} GFLOP/sample fwd+bwd of the REFERENCE step (dense '
+                                     'graph product), the count rounds 1-2 quoted as `frac`'}
         if not args.no_microbench:
             line['kernels'] = kernel_microbench(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -197,6 +197,30 @@ class _GraphConv(Function):
         return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None
 
 
+def grad_kernel_mfma_flops(tables, batch, frames):
+    """MFMA FLOPs the weight- and adjacency-gradient kernels issue per launch (for the roofline accounting of
+    bench.py; one v_mfma_f32_16x16x4_f32 = 2048 FLOP).  Kept next to the launches so that it changes with them.
+
+    gcn_dw_kernel: 4-frame tiles; a (plane, group of four joints) unit is live when any of its joints has a non-empty
+    row list, and then costs 16 MFMAs in each of the four ci-column waves.
+    gcn_dcoef_kernel: tiles of F = 384 // V frames, joint-major n-tiles of 16 columns; a (plane, n-tile) unit is live
+    when any of its columns' joints has a non-empty row list: 16 k-steps x 4 m-tiles."""
+    import numpy as np
+    K, V = tables.K, tables.V
+    gidx = tables.gidx_r.numpy()
+    lofs = np.concatenate([[0], np.cumsum(tables.Lk_r)])
+    live = np.stack([(gidx[lofs[k]:lofs[k + 1]] >= 0).any(0) for k in range(K)])        # [K][V]
+    groups = sum(int(live[k, 4 * g:4 * g + 4].any()) for k in range(K) for g in range((V + 3) // 4))
+    dw = groups * 64 * 2048.0 * batch * ((frames + 3) // 4)
+    F = min(384 // V, frames)
+    units = 0
+    for t in range(24):
+        joints = sorted({c // F for c in range(16 * t, 16 * t + 16) if c < F * V})
+        units += sum(int(live[k, joints].any()) for k in range(K)) if joints else 0
+    dc = units * 64 * 2048.0 * batch * ((frames + F - 1) // F)
+    return {'gcn_weight_grad': dw, 'gcn_coef_grad': dc}
+
+
 def supported(x, weight, A):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64
             and weight.shape[1] == 64 and weight.shape[0] == 64 * A.shape[0] and A.shape[0] == 11

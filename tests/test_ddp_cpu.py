@@ -30,8 +30,10 @@ def _worker(rank, world, port, out):
     with cpu_ops():
         losses = trainer.train_step(make_batch(2, 32, seed=50, rank=rank))
     sd = {k: v.clone() for k, v in net.module.state_dict().items()}
+    # after the step p.grad still holds what the optimizer consumed: the gradient averaged over the two ranks
+    grads = {k: p.grad.clone() for k, p in net.module.named_parameters() if p.grad is not None}
     torch.save({'loss': losses, 'w': sd['backbone.st_gcn_networks.0.gcn.conv.weight'],
-                'mu': sd['detection.gmm_heading.mdn.mu']}, os.path.join(out, f'r{rank}.pt'))
+                'mu': sd['detection.gmm_heading.mdn.mu'], 'grads': grads}, os.path.join(out, f'r{rank}.pt'))
     # reduce_dict averages across ranks
     r = reduce_dict({'a': torch.tensor(float(rank)), 'b': torch.tensor(2.0 * rank)})
     assert abs(r['a'].item() - 0.5) < 1e-6 and abs(r['b'].item() - 1.0) < 1e-6
@@ -61,3 +63,46 @@ def test_ddp_two_ranks_gloo(tmp_path):
     assert a['loss'].keys() == b['loss'].keys() and len(a['loss']) == 10
     for k in a['loss']:
         assert abs(a['loss'][k] - b['loss'][k]) < 1e-9
+    # ... and the step equals ONE process that runs the two shards one after the other (each with its own BatchNorm
+    # batch statistics, as under DDP without SyncBN) and averages the two gradients (net_utils/utils.py:250-251 of the
+    # reference wraps the net in DistributedDataParallel, whose contract this is)
+    want, want_loss = _single_process_average()
+    assert set(want) == set(a['grads'])
+    for k, g in want.items():
+        scale = g.abs().max().item()
+        # gradients that are zero in exact arithmetic (conv biases in front of a train-mode BatchNorm) are rounding
+        # noise on both sides
+        if scale < 1e-6:
+            continue
+        err = (a['grads'][k].double() - g.double()).abs().max().item()
+        assert err <= 1e-4 * scale, f'{k}: DDP gradient differs from the averaged single-process gradient by {err:.2e} (scale {scale:.2e})'
+        assert torch.equal(a['grads'][k], b['grads'][k]), k
+    for k in want_loss:
+        assert abs(a['loss'][k] - want_loss[k]) <= 1e-5 * max(1.0, abs(want_loss[k])), k
+
+
+def _single_process_average():
+    """The two shards of the DDP test through one un-wrapped network: mean of the two gradients and of the logged
+    scalars."""
+    sys.path.insert(0, ROOT)
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    torch.set_num_threads(2)
+    cfg = P2RConfig(default_config('train', data={'num_frames': 32}), device='cpu')
+    torch.manual_seed(42)
+    net = METHODS.get('P2RNet')(cfg)
+    total, losses = {}, {}
+    with cpu_ops():
+        for rank in (0, 1):
+            torch.manual_seed(7)
+            net.zero_grad()
+            batch = make_batch(2, 32, seed=50, rank=rank)
+            loss = net.loss(net(batch), batch)
+            loss['total'].backward()
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    total[k] = total.get(k, 0) + p.grad.detach().clone() / 2
+            for k, v in loss.items():
+                losses[k] = losses.get(k, 0.0) + float(v.detach()) / 2
+    return total, losses

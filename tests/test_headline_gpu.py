@@ -1,0 +1,101 @@
+"""GPU: the BENCHMARKED shape (BASELINE configs[2]: bs=32, T=1024, J=53) as a parity test, not only as a bench.
+
+At this size the persistent-workgroup kernels walk 2048 tiles with 256 workgroups and 32 sequences -- index
+arithmetic the small test shapes never reach.  The ST-GCN backbone on the fused HIP kernels (train mode: graph conv
+forward / dX / dW / dA, temporal conv, BatchNorm passes and epilogue statistics, embedding MLPs) is compared with
+the SAME weights run through plain torch modules (the reference's formulation: conv1x1 to 704 channels + einsum,
+nn.BatchNorm2d, nn.Conv2d) on the same GPU: seed features and every backbone parameter gradient.  A mis-indexed tile
+shows as an O(1) error; the tolerances (1e-3 forward, 5e-3 backward of each tensor's largest entry) only absorb
+train-mode BatchNorm's amplification of fp32 summation-order noise over six blocks."""
+import contextlib
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _plain_torch(net):
+    """Every fused dispatch of the backbone switched off: the host modules run as plain torch chains."""
+    from pose2room_amd.p2rnet import bn_op, tconv_op
+    saved = (bn_op.supported, tconv_op.supported_embed3)
+    bn_op.supported = lambda *a, **k: False
+    tconv_op.supported_embed3 = lambda *a, **k: False
+    for b in net.backbone.st_gcn_networks:
+        b.gcn.fused = False
+        b.fused_bn = False
+        b.fused_tconv = False
+    try:
+        yield
+    finally:
+        bn_op.supported, tconv_op.supported_embed3 = saved
+
+
+def test_backbone_at_bench_shape_fused_vs_plain(dev):
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    B, T = 32, 1024
+    cfg = P2RConfig(default_config('train', data={'num_frames': T}), device=dev)
+    torch.manual_seed(42)
+    net = METHODS.get('P2RNet')(cfg).to(dev).train()
+    ref = copy.deepcopy(net)
+    joints = make_batch(B, T, seed=1234, device=dev)['input_joints']
+    g = torch.Generator().manual_seed(5)
+    go = torch.randn(B, 512, 256, generator=g).to(dev)
+
+    def run(model):
+        ep = model.backbone(joints, {})
+        sf = ep['seed_features']
+        sf.backward(go)
+        grads = {k: p.grad.detach().clone() for k, p in model.backbone.named_parameters() if p.grad is not None}
+        return ep['seed_inds'].clone(), sf.detach().clone(), grads
+
+    inds_a, sf_a, g_a = run(net)
+    with _plain_torch(ref):
+        inds_b, sf_b, g_b = run(ref)
+    torch.cuda.synchronize()
+    assert torch.equal(inds_a, inds_b)
+    assert torch.isfinite(sf_a).all()
+    scale = sf_b.abs().max().item()
+    err = (sf_a - sf_b).abs().max().item()
+    assert err <= 1e-3 * scale, f'seed_features: {err:.3e} vs scale {scale:.3e}'
+    assert set(g_a) == set(g_b) and len(g_a) > 60
+    worst = {}
+    for k in g_b:
+        # zero in exact arithmetic (conv bias in front of a train-mode BatchNorm): rounding noise on both sides
+        if k.endswith('gcn.conv.bias') or k.endswith('tcn.2.bias') or (k.endswith('conv.bias') and 'embed' in k):
+            continue
+        s = g_b[k].abs().max().item()
+        if s < 1e-8:
+            continue
+        worst[k] = (g_a[k] - g_b[k]).abs().max().item() / s
+    bad = {k: v for k, v in worst.items() if not v <= 5e-3}
+    print('bench-shape backbone: worst relative gradient error', max(worst.values()), max(worst, key=worst.get))
+    assert not bad, bad
+
+
+def test_train_step_at_bench_shape(dev):
+    """One full train step at bs=32, T=1024: finite losses, parameters move, and the fused detection loss equals its
+    torch composition on the very tensors of that step."""
+    import math
+    import bench
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    trainer, cfg = bench.build_trainer(dev, 1024, 1)
+    batch = make_batch(32, 1024, seed=1234, device=dev)
+    before = {k: v.detach().clone() for k, v in trainer.net.module.named_parameters()}
+    out = trainer.train_step(dict(batch))
+    assert all(math.isfinite(v) for v in out.values()), out
+    moved = sum(int(not torch.equal(before[k], v)) for k, v in trainer.net.module.named_parameters())
+    assert moved > 100
+    net = trainer.net.module
+    with torch.no_grad():
+        est = net(batch)
+        fused = net.detection_loss(est, batch, None)
+        comp = net.detection_loss.composed(est, batch, None)
+    for k in comp:
+        a, b = float(fused[k]), float(comp[k])
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (k, a, b)
+    v = bench.verify_bench_shape(trainer, batch)
+    assert v['losses_finite'] and v['seed_inds_equal']
