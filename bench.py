@@ -226,9 +226,13 @@ def verify_bench_shape(trainer, batch):
     was_training = net.training
     net.eval()
     try:
+        def front(data):      # backbone -> votes -> vote aggregation (no mixture heads: they draw noise in training)
+            xyz, features, ep = net._votes(data)
+            net.detection._aggregate(xyz, features, ep)
+            return ep
         with torch.no_grad():
-            full = net.generate_end_points(batch)
-            one = net.generate_end_points({k: (v[:1].contiguous() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            full = front(batch)
+            one = front({k: (v[:1].contiguous() if torch.is_tensor(v) else v) for k, v in batch.items()})
     finally:
         net.train(was_training)
     assert torch.equal(full['seed_inds'][:1], one['seed_inds']), 'seed_inds of sample 0 differ between B and 1'
@@ -428,6 +432,10 @@ def main():
     step_h2d()
     elapsed_h2d, _, step_ms_h2d = timed(step_h2d)
 
+    # instrumented steps (events around the MFMA kernels' launches): every rank runs them -- they contain the gradient
+    # all-reduce -- rank 0 reports
+    roof, rows = mfma_rooflines(trainer, batch, args.batch, args.frames)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         sps = world * args.batch * args.steps / elapsed
@@ -450,7 +458,6 @@ def main():
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
             'verify': verify,
         }
-        roof, rows = mfma_rooflines(trainer, batch, args.batch, args.frames)
         line['roofline'] = roof
         line['mfma_kernels'] = rows
         issued, src = step_mfma_issued(args.batch, args.frames)

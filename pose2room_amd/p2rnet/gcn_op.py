@@ -224,7 +224,7 @@ def grad_kernel_mfma_flops(tables, batch, frames):
 def supported(x, weight, A):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64
             and weight.shape[1] == 64 and weight.shape[0] == 64 * A.shape[0] and A.shape[0] == 11
-            and A.shape[1] <= 64)
+            and A.shape[1] <= 56)      # the weight-gradient kernel stages 4 frames x V <= 226 columns per row
 
 
 def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None, prepared=None):

@@ -129,8 +129,12 @@ class BoxNetDetectionLoss(BaseLoss):
 
     # loss.py:152-189
     def __call__(self, est_data, gt_data, dataset_config):
-        if fused_supported(est_data, gt_data):
-            return fused_detection_loss(est_data, gt_data, self.origin_joint_id)
+        if est_data['vote_xyz'].is_cuda:
+            # the HIP ops read raw pointers: bring every tensor to the dtype they expect (no-op for the tensors the
+            # loader and the network produce), then route on what the fused kernel can hold
+            est_data, gt_data = _canonical_dtypes(est_data, gt_data)
+            if fused_supported(est_data, gt_data):
+                return fused_detection_loss(est_data, gt_data, self.origin_joint_id)
         return self.composed(est_data, gt_data, dataset_config)
 
     def composed(self, est_data, gt_data, dataset_config):
@@ -159,6 +163,18 @@ _F32_EST = ('vote_xyz', 'objectness_scores', 'center', 'size', 'sem_cls_scores',
             'aggregated_vote_xyz')
 _F32_GT = ('vote_label', 'center_label', 'box_label_mask', 'size', 'heading')
 _MAX_GT, _DL_T, _DL_NPART = 32, 256, 12        # csrc/det_loss.hip: DL_MAXG, DL_T, DL_NPART
+
+
+def _canonical_dtypes(est_data, gt_data):
+    """Shallow copies of the two dicts with the loss inputs in the dtypes of the reference pipeline: f32 floats, the
+    f64 heading head, int64 masks / labels.  Casts are differentiable (`.to`) and skipped when already right."""
+    est, gt = dict(est_data), dict(gt_data)
+    for d, names, dt in ((est, _F32_EST, torch.float32), (gt, _F32_GT, torch.float32), (est, ('heading',), torch.float64),
+                         (gt, ('vote_label_mask', 'sem_cls_label'), torch.int64)):
+        for n in names:
+            if torch.is_tensor(d.get(n)) and d[n].dtype != dt:
+                d[n] = d[n].to(dt)
+    return est, gt
 
 
 def fused_supported(est_data, gt_data):

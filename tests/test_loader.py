@@ -100,3 +100,61 @@ def test_demo_forward_gpu(tmp_path, dev):
     net = net.to(dev).eval()
     with torch.no_grad():
         check_demo(net, _demo_data(tmp_path, dev))
+
+
+def test_read_sample_hdf5_through_in_memory_file(monkeypatch):
+    """`read_sample_hdf5` cannot meet a real .hdf5 here (no h5py in the image): an in-memory stand-in with the h5py
+    surface it touches -- File(path, 'r') as context manager, group['name'], dataset[:] / dataset[0], .values() --
+    walks its eight lines over the sample layout of utils/virtualhome/3_generate_samples.py:176-193 and the result
+    goes through the numeric loader like a file would (reference dataloader.py:85-97)."""
+    import sys
+    import types
+    joints, votes, inst = _sample()
+
+    class _DS(object):
+        def __init__(self, a):
+            self.a = np.asarray(a)
+
+        def __getitem__(self, k):
+            return self.a[k]
+
+    class _Group(dict):
+        pass
+
+    opened = []
+
+    class _File(_Group):
+        def __init__(self, path, mode):
+            opened.append((path, mode))
+            self['skeleton_joints'] = _DS(joints)
+            self['skeleton_joint_votes'] = _DS(votes)
+            nodes = _Group()
+            for i, n in enumerate(inst):
+                g = _Group(class_id=_DS([n['class_id']]), centroid=_DS(n['centroid']), R_mat=_DS(n['R_mat']),
+                           size=_DS(n['size']))
+                nodes[str(i)] = g
+            self['object_nodes'] = nodes
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    fake = types.ModuleType('h5py')
+    fake.File = _File
+    monkeypatch.setitem(sys.modules, 'h5py', fake)
+    j, v, nodes = dl.read_sample_hdf5('/data/samples/7_0_0.hdf5')
+    assert opened == [('/data/samples/7_0_0.hdf5', 'r')]
+    np.testing.assert_array_equal(j, joints)
+    np.testing.assert_array_equal(v, votes)
+    assert len(nodes) == len(inst)
+    for a, b in zip(nodes, inst):
+        assert a['class_id'] == b['class_id']
+        for k in ('centroid', 'R_mat', 'size'):
+            np.testing.assert_array_equal(a[k], b[k])
+    want = dl.sample_to_tensors(joints, votes, inst, 16, sample_idx='s')
+    got = dl.sample_to_tensors(j, v, nodes, 16, sample_idx='s')
+    for k in want:
+        if isinstance(want[k], np.ndarray):
+            np.testing.assert_array_equal(got[k], want[k])

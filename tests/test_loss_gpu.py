@@ -123,10 +123,12 @@ def test_fused_loss_dispatch_falls_back(dev):
     want = loss_fn.composed(est, gt, None)
     gt64 = dict(gt, center_label=gt['center_label'].double())
     assert not L.fused_supported(est, gt64)
-    got = loss_fn(est, gt64, None)                       # routed to `composed`
-    np.testing.assert_allclose(got['total'].item(), want['total'].item(), rtol=1e-6)
+    got = loss_fn(est, gt64, None)                       # cast to the kernel's dtypes first, not misread
+    np.testing.assert_allclose(got['total'].item(), want['total'].item(), rtol=1e-5)
     half = dict(est, center=est['center'].half())
     assert not L.fused_supported(half, gt)
+    got = loss_fn(half, gt, None)
+    assert got['center_loss'].dtype == torch.float32 and torch.isfinite(got['total'])
     # 40 ground-truth slots (8 more than the kernel's table): composed form, same value as 10 slots + padding
     pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], 30, *t.shape[2:], dtype=t.dtype, device=dev)], 1)
     gt40 = dict(gt, **{k: pad(gt[k]) for k in ('center_label', 'box_label_mask', 'size', 'heading', 'sem_cls_label')})
