@@ -219,6 +219,21 @@ int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x,
                            int *n_partials, const float *bwd_u, const unsigned char *bwd_mask,
                            const float *bwd_fin, void *stream_h);
 
+/* Third generation of the same operator (csrc/stgcn_gcn3.hip): the data movement of the second generation with the
+ * per-wave work list resolved at BUILD time (tools/gen_gcn_sched.py -> csrc/gcn3_sched.inc): accumulator slots,
+ * source joints and coefficient-table indices are immediates of a straight-line program per wave; no work stream,
+ * no fill pre-launch.  The schedule is generated for the P2RNet skeleton (stgcn_layers.py:151-205: 53 joints, 11
+ * planes); p2r_stgcn_gcn3_signature(form) returns the 64-bit signature of the neighbour-table pattern of
+ * form 0 (column lists, forward) / 1 (row lists, data gradient) -- pose2room_amd.p2rnet.gcn_tables.pattern_signature
+ * of the caller's tables must equal it, every other adjacency goes through p2r_stgcn_gcn2_forward.
+ * Arguments as p2r_stgcn_gcn2_forward without the stream; additionally T % 16 == 0 and x, z, addend 16-byte aligned
+ * (P2R_EINVAL otherwise: use the second generation). */
+unsigned long long p2r_stgcn_gcn3_signature(int form);
+int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const float *x, const float *Wp,
+                           const float *coef, const float *bias_cv, const float *addend, float *z,
+                           float *stats_partial, int *n_partials, const float *bwd_u,
+                           const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h);
+
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
  * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over
  * all columns of dz[a][col] * G_k[b][col] at [k][a][b], to be summed over the leading axis by the

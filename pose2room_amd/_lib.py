@@ -44,7 +44,9 @@ def lib():
             raise P2RLibraryError("libp2r_hip.so ABI version mismatch")
         for name in declared_symbols():
             fn = getattr(l, name)
-            if name not in ("p2r_build_arch",):
+            if name == "p2r_stgcn_gcn3_signature":
+                fn.restype = ctypes.c_uint64
+            elif name not in ("p2r_build_arch",):
                 fn.restype = ctypes.c_int
         _lib = l
     return _lib

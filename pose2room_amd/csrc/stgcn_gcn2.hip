@@ -302,7 +302,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
             if (short_rec) gather(NE2{}, n0, xl, xv);
             else gather(NE6{}, n0, xl, xv);
 #endif
+#ifdef G2X_SLOAD
+            // the record after next: requested HERE, ahead of the MFMA run (left to the compiler the scalar loads end
+            // up behind it, followed at once by the wait for them); consumed behind the run, after an explicit wait
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            i32x4 q0, q1, q2;
+            {
+              const int4 *rp = st + 3 * u + 6;
+              asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
+                           : "=&s"(q0), "=&s"(q1), "=&s"(q2) : "s"(rp) : "memory");
+            }
+#else
             const int4 m0 = st[3 * u + 6], m1 = st[3 * u + 7], m2 = st[3 * u + 8];
+#endif
             __builtin_amdgcn_sched_barrier(0);       // all LDS reads are requested before the MFMAs ...
 #ifndef G2X_NOMFMA
 #ifdef G2X_MFMAX
@@ -318,6 +330,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
             acc[i][0][0] += b_cur[0] + b_cur[1] + b_cur[2] + b_cur[3] + a[0][0];
 #endif
             __builtin_amdgcn_sched_barrier(0);       // ... and consumed after them: no s_waitcnt inside the MFMA run
+#ifdef G2X_SLOAD
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2) : : "memory");
+            const int4 m0 = make_int4(q0.x, q0.y, q0.z, q0.w), m1 = make_int4(q1.x, q1.y, q1.z, q1.w),
+                       m2 = make_int4(q2.x, q2.y, q2.z, q2.w);
+#endif
 #ifndef G2X_NOGATHER
             if (short_rec) combine(NE2{}, n1, n2, xv, b_cur);
             else combine(NE6{}, n1, n2, xv, b_cur);

@@ -41,7 +41,21 @@ class GraphTables:
                 self.stream_c, self.stream_r = torch.from_numpy(sc), torch.from_numpy(sr)
             except gcn_tables.StreamBudgetError:
                 pass
+        # third generation (csrc/stgcn_gcn3.hip): statically scheduled for ONE pattern, the P2RNet skeleton's; taken
+        # when the signatures of both table forms equal the ones the library was generated for
+        self._gen3 = None
         self._dev = {}
+
+    @property
+    def gen3(self):
+        if self._gen3 is None:
+            ok = False
+            if self.gen2:
+                lib = _lib.lib()
+                ok = (gcn_tables.pattern_signature(self.nbr_c, self.gidx_c, self.Lk_c) == lib.p2r_stgcn_gcn3_signature(0)
+                      and gcn_tables.pattern_signature(self.nbr_r, self.gidx_r, self.Lk_r) == lib.p2r_stgcn_gcn3_signature(1))
+            self._gen3 = ok
+        return self._gen3
 
     @property
     def gen2(self):
@@ -82,9 +96,19 @@ def permute_planes(W3):
     return W3.reshape(K, 4, 16, 4, 4, 4).permute(0, 3, 1, 5, 2, 4).contiguous()     # (k, ph, m, g, r, s)
 
 
-def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None):
+USE_GEN3 = True      # statically scheduled kernel for the P2RNet skeleton (tests switch it off to reach gcn2)
+
+
+def _gen3_able(x, z, addend, tables):
+    return (USE_GEN3 and tables.gen3 and x.shape[2] % 16 == 0 and x.data_ptr() % 16 == 0 and z.data_ptr() % 16 == 0
+            and (addend is None or addend.data_ptr() % 16 == 0))
+
+
+def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None, form=None):
     """bwd = (u, mask, fin): data-gradient launch whose statistics epilogue is the reduction pass of the
-    BatchNorm + residual + ReLU backward of the block in front (implies want_stats; see bn_op.BNLink)."""
+    BatchNorm + residual + ReLU backward of the block in front (implies want_stats; see bn_op.BNLink).
+    form: 0 column lists (forward) / 1 row lists (data gradient) when known -- the statically scheduled third-generation
+    kernel then takes the launch if the tables carry the pattern it was generated for; `stream` is for gcn2."""
     N, C, T, V = x.shape
     z = torch.empty_like(x)
     lib = _lib.lib()
@@ -94,6 +118,13 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
         st = _lib.current_stream(x.device)
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
+        if form is not None and _gen3_able(x, z, addend, tables):
+            bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
+            _lib.check(lib.p2r_stgcn_gcn3_forward(N, T, V, tables.K, ltot, int(form), _lib.ptr(x), _lib.ptr(Wp),
+                                                  _lib.ptr(coef), _lib.ptr(bias_cv), _lib.ptr(addend), _lib.ptr(z),
+                                                  _lib.ptr(part), None, _lib.ptr(bu), _lib.ptr(bm), _lib.ptr(bf), st),
+                       "stgcn_gcn3_forward")
+            return (z, part) if want_stats else z
         work = torch.empty_like(stream)       # the stream with this call's coefficients (scalar-loaded by the kernel)
         bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
         _lib.check(lib.p2r_stgcn_gcn2_forward(N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef),
@@ -114,7 +145,7 @@ class _GraphConv(Function):
         W = weight.contiguous()
         if tables.gen2:         # second-generation kernel (csrc/stgcn_gcn2.hip)
             out = _gcn2_forward(x, wp_f if wp_f is not None else permute_planes(W.view(tables.K, 64, 64)),
-                                coef_c.contiguous(), t['stream_c'], bias_cv.contiguous(), tables, want_stats)
+                                coef_c.contiguous(), t['stream_c'], bias_cv.contiguous(), tables, want_stats, form=0)
         else:
             out = _gcn_forward(x, W, t['nbr_c'], coef_c.contiguous(), tables.LkA_c, bias_cv.contiguous(), tables,
                                want_stats)
@@ -150,7 +181,8 @@ class _GraphConv(Function):
                 wp_b = ctx.wp_b if ctx.wp_b is not None else permute_planes(W.view(K, C, C).transpose(1, 2))
                 dx = _gcn2_forward(dz, wp_b, coef_r.contiguous(),
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,
-                                   want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None)
+                                   want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None,
+                                   form=1)
                 if use_link:
                     # dx is the whole gradient of the previous block's output: its BatchNorm backward takes the
                     # two per-channel sums from here instead of a pass over dx and its saved input

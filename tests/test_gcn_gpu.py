@@ -14,7 +14,9 @@ def _reference(x, weight, bias, Aeff):
     return torch.einsum('nkctv,kvw->nctw', y.view(n, K, kc // K, t, v), Aeff)
 
 
-@pytest.mark.parametrize("N,T", [(1, 1), (2, 7), (1, 20), (3, 33), (2, 130), (5, 1000)])   # (5,1000): 315 tiles > 256 persistent workgroups, ragged last tile
+# (5,1000): 315 tiles > 256 persistent workgroups, ragged last tile (second generation); T % 16 == 0: the statically
+# scheduled third generation, (5,1008) with more tiles than workgroups
+@pytest.mark.parametrize("N,T", [(1, 1), (2, 7), (1, 20), (3, 33), (2, 130), (5, 1000), (1, 16), (3, 48), (2, 256), (5, 1008)])
 def test_graph_conv_forward_backward(dev, N, T):
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     from pose2room_amd.p2rnet import gcn_op
@@ -297,3 +299,67 @@ def test_gcn2_misaligned_addend_and_output(dev):
     z1 = gcn_op._gcn2_forward(x, wp, coef, t['stream_c'], bias, tables, addend=add_mis)
     torch.cuda.synchronize()
     assert torch.equal(z0, z1)
+
+
+@pytest.mark.parametrize("N,T", [(1, 16), (3, 64), (9, 480)])
+def test_gcn3_static_schedule_equals_gcn2(dev, N, T):
+    """The statically scheduled kernel (csrc/stgcn_gcn3.hip, schedule generated at build time) and the run-time work
+    stream of the second generation perform the same fmaf / MFMA chain per output element: bit-identical outputs and
+    epilogue sums, forward and data gradient (with addend and the BatchNorm-backward epilogue)."""
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    assert tables.gen3, "the library's static schedule was not generated for the P2RNet skeleton (tools/gen_gcn_sched.py)"
+    t = tables.on(dev)
+    g = torch.Generator().manual_seed(N * 7 + T)
+    x = torch.randn(N, 64, T, V, generator=g).to(dev)
+    Wp = gcn_op.permute_planes((torch.randn(K, 64, 64, generator=g) / 8).to(dev))
+    Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
+    bias = torch.randn(64, V, generator=g).to(dev)
+    add = torch.randn(N, 64, T, V, generator=g).to(dev)
+    u = torch.randn(N, 64, T, V, generator=g).to(dev)
+    mask = (torch.rand(N, 64, T, V, generator=g) > 0.4).to(torch.uint8).to(dev)
+    fin = torch.randn(4, 64, generator=g).to(dev)
+    cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+    cases = [dict(coef=cc, stream=t['stream_c'], bias_cv=bias, want_stats=True, form=0),
+             dict(coef=cr, stream=t['stream_r'], bias_cv=None, form=1),
+             dict(coef=cr, stream=t['stream_r'], bias_cv=None, addend=add, want_stats=True, bwd=(u, mask, fin), form=1)]
+    try:
+        for kw in cases:
+            kw = dict(kw)
+            coef, stream, bias_cv = kw.pop('coef'), kw.pop('stream'), kw.pop('bias_cv')
+            outs = []
+            for gen3 in (False, True):
+                gcn_op.USE_GEN3 = gen3
+                outs.append(gcn_op._gcn2_forward(x, Wp, coef, stream, bias_cv, tables, **kw))
+            torch.cuda.synchronize()
+            a, b = outs
+            if isinstance(a, tuple):
+                assert torch.equal(a[0], b[0])
+                assert torch.equal(a[1].sum(0), b[1].sum(0)) or torch.allclose(a[1].double().sum(0), b[1].double().sum(0), rtol=1e-6)
+            else:
+                assert torch.equal(a, b)
+    finally:
+        gcn_op.USE_GEN3 = True
+
+
+def test_gcn3_falls_back_for_other_patterns_and_ragged_lengths(dev):
+    """A 53-joint adjacency with another pattern, and sequence lengths that are not multiples of 16, run on the second
+    generation (work stream built at run time)."""
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A.copy()
+    A[3, 5, 7] = 0.5                              # one more link than the skeleton has
+    tables = gcn_op.GraphTables(A)
+    assert tables.gen2 and not tables.gen3
+    K, V = A.shape[0], A.shape[1]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 32, V, generator=g)
+    w = torch.randn(K * 64, 64, generator=g) / 8
+    At = torch.tensor(A, dtype=torch.float32)
+    zr = _reference(x.double(), w.double(), None, At.double())
+    z = gcn_op.graph_conv(x.to(dev), w.to(dev), None, At.to(dev), tables)
+    assert (z.double().cpu() - zr).abs().max().item() <= 2e-5 * zr.abs().max().item()
