@@ -234,6 +234,16 @@ int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const
                            float *stats_partial, int *n_partials, const float *bwd_u,
                            const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h);
 
+/* Adjacency gradient at the row-list entries, statically scheduled like p2r_stgcn_gcn3_forward
+ * (csrc/stgcn_gcn3_grad.hip; requires p2r_stgcn_gcn3_signature(1) == signature of the caller's row tables):
+ *   dcoef[lofs_k + j][v] = sum over (n, t, c) of (W_k . x)[c, t, v] * dz[c, t, w_j(k, v)]
+ * x, dz (N,64,T,53); Wp [K][4][4][64][4] = the forward planes in kernel order; dcoef_partial
+ * [n_blocks][ltot][53] per-workgroup sums, summed over the leading axis by the caller.  T % 16 == 0, dz 16-byte
+ * aligned (P2R_EINVAL otherwise: use p2r_stgcn_gcn_coef_grad).  Replaces the autograd of the einsum
+ * w.r.t. `A * edge_importance` (stgcn_layers.py:62-65, stgcn.py:134). */
+int p2r_stgcn_gcn3_coef_grad(int N, int T, int V, int K, int ltot, const float *x, const float *dz,
+                             const float *Wp, int n_blocks, float *dcoef_partial, void *stream);
+
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
  * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over
  * all columns of dz[a][col] * G_k[b][col] at [k][a][b], to be summed over the leading axis by the

@@ -153,6 +153,7 @@ class _GraphConv(Function):
         ctx.tables = tables
         ctx.bn_link = bn_link
         ctx.wp_b = wp_b            # planes of the data gradient, already in kernel order (prepare_chain), or None
+        ctx.wp_f = wp_f            # forward planes in kernel order: the adjacency-gradient kernel multiplies by them
         ctx.n_out = 2 if want_stats else 1
         if want_stats:
             ctx.mark_non_differentiable(out[1])
@@ -215,9 +216,15 @@ class _GraphConv(Function):
                 # leave ~20 % of the (plane, 16-column) units empty, which the kernel skips
                 ltot = coef_r.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
-                _lib.check(lib.p2r_stgcn_gcn_coef_grad(
-                    N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(W), _lib.ptr(t['nbr_r']),
-                    _lib.ptr(t['real_r']), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
+                if USE_GEN3 and tables.gen3 and T % 16 == 0 and dz.data_ptr() % 16 == 0:
+                    # statically scheduled kernel (csrc/stgcn_gcn3_grad.hip)
+                    wp_f = ctx.wp_f if ctx.wp_f is not None else permute_planes(W.view(K, C, C))
+                    _lib.check(lib.p2r_stgcn_gcn3_coef_grad(N, T, V, K, ltot, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(wp_f),
+                                                            _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn3_coef_grad")
+                else:
+                    _lib.check(lib.p2r_stgcn_gcn_coef_grad(
+                        N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(W), _lib.ptr(t['nbr_r']),
+                        _lib.ptr(t['real_r']), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
                 dcoef_r = part.sum(0)
         if ctx.needs_input_grad[4] and dbias is None:
             part = torch.empty((N * C, V), dtype=torch.float32, device=dev)

@@ -363,3 +363,35 @@ def test_gcn3_falls_back_for_other_patterns_and_ragged_lengths(dev):
     zr = _reference(x.double(), w.double(), None, At.double())
     z = gcn_op.graph_conv(x.to(dev), w.to(dev), None, At.to(dev), tables)
     assert (z.double().cpu() - zr).abs().max().item() <= 2e-5 * zr.abs().max().item()
+
+
+@pytest.mark.parametrize("N,T", [(1, 16), (2, 64), (5, 1008)])
+def test_gcn3_adjacency_gradient(dev, N, T):
+    """Statically scheduled adjacency-gradient kernel (csrc/stgcn_gcn3_grad.hip) against the fp64 definition
+    dA[k][v][w] = sum_{n,c,t} (W_k x)[n,c,t,v] dz[n,c,t,w] at the row-list entries, and padded slots exactly zero."""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K, V = A.shape[0], A.shape[1]
+    tables = gcn_op.GraphTables(A)
+    assert tables.gen3
+    t = tables.on(dev)
+    g = torch.Generator().manual_seed(N + T)
+    x = torch.randn(N, 64, T, V, generator=g).to(dev)
+    dz = torch.randn(N, 64, T, V, generator=g).to(dev)
+    W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
+    ltot = t['gidx_r'].shape[0]
+    part = torch.empty(256, ltot, V, device=dev)
+    _lib.check(_lib.lib().p2r_stgcn_gcn3_coef_grad(N, T, V, K, ltot, _lib.ptr(x), _lib.ptr(dz),
+                                                   _lib.ptr(gcn_op.permute_planes(W)), 256, _lib.ptr(part),
+                                                   _lib.current_stream(dev)), "gcn3_coef_grad")
+    got = part.double().sum(0)
+    dA = torch.zeros(K, V, V, dtype=torch.float64, device=dev)
+    for n in range(N):                                         # sample by sample: bounded fp64 intermediates
+        Y = torch.einsum('kcd,dtv->kctv', W.double(), x[n].double())
+        dA += torch.einsum('kctv,ctw->kvw', Y, dz[n].double())
+    gi = t['gidx_r']
+    want = torch.where(gi >= 0, dA.reshape(-1)[gi.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=dev))
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert (got[gi < 0] == 0).all()

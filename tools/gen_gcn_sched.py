@@ -116,6 +116,33 @@ def emit_form(form, nbr, gidx, Lk, out):
     return n_units
 
 
+def emit_coef_grad(nbr, gidx, Lk, out):
+    """Adjacency-gradient kernel (gcn3_dcoef_kernel): the row-list schedule with every step carrying its OWN entries
+    (the step's MFMAs produce Y_k of one (plane, joint) unit, reduced at once against the gathered rows)."""
+    waves = schedule(nbr, gidx, Lk)
+    out.append('// ---- adjacency gradient (row lists): D3_VISIT(set, plane, next, wrap, piece), '
+               'D3_STEP(set, slot, ne, o0,c0, .. o5,c5), D3_CONT(ne, o0,c0, ..), D3_END(parity, pieces)')
+    for w, (owner, visits) in enumerate(waves):
+        lines = []
+        nvis = len(visits)
+        for vi, (k, steps) in enumerate(visits):
+            wrap = vi + 1 >= nvis
+            nk = visits[0][0] if wrap else visits[vi + 1][0]
+            piece = vi if vi < PIECES_PER_WAVE else -1
+            lines.append('D3_VISIT(%d, %d, %d, %d, %d)' % (vi & 1, k, nk, int(wrap), piece))
+            prev = None
+            for slot, ent in steps:
+                if slot == prev:      # rest of a list longer than six entries: same product, no new MFMAs
+                    lines.append('D3_CONT(%d, %s)' % (len(ent), fmt_entries(ent)))
+                else:
+                    lines.append('D3_STEP(%d, %d, %d, %s)' % (vi & 1, slot, len(ent), fmt_entries(ent)))
+                prev = slot
+        lines.append('D3_END(%d, %d)' % (nvis & 1, min(nvis, PIECES_PER_WAVE)))
+        out.append(f'#define D3_BODY_{w} \\')
+        out.append(' \\\n'.join('  ' + l for l in lines))
+        out.append('')
+
+
 def fmt_entries(ent):
     """Six (LDS byte offset of the source joint, coefficient-table index) pairs, padded with (0, -1)."""
     pad = list(ent) + [(0, -1)] * (CHUNK - len(ent))
@@ -142,6 +169,8 @@ def main():
     for form, tr in ((0, False), (1, True)):
         nbr, gidx, Lk = gcn_tables.build(A, transpose=tr)
         emit_form(form, nbr, gidx, Lk, out)
+        if form == 1:
+            emit_coef_grad(nbr, gidx, Lk, out)
     path = os.path.join(ROOT, 'pose2room_amd', 'csrc', 'gcn3_sched.inc')
     with open(path, 'w') as f:
         f.write('\n'.join(out) + '\n')
