@@ -125,7 +125,9 @@ def _null(a):
 
 # entry point -> tag of the launch (None: not timed).  Argument positions as in include/p2r_hip.h.
 _TIMED = {
-    'p2r_stgcn_gcn2_forward': lambda a: None if _null(a[12]) else ('gcn2_data_gradient' if _null(a[10]) else 'gcn2_forward'),
+    'p2r_stgcn_gcn3_forward': lambda a: None if _null(a[11]) else ('gcn_data_gradient' if a[5] == 1 else 'gcn_forward'),
+    'p2r_stgcn_gcn3_coef_grad': lambda a: 'gcn_coef_grad',
+    'p2r_stgcn_gcn2_forward': lambda a: None if _null(a[12]) else ('gcn_data_gradient' if _null(a[10]) else 'gcn_forward'),
     'p2r_stgcn_gcn_weight_grad': lambda a: None if _null(a[10]) else 'gcn_weight_grad',
     'p2r_stgcn_gcn_coef_grad': lambda a: 'gcn_coef_grad',
     'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv2_data_gradient' if _null(a[5]) else 'tconv2_forward'),
@@ -147,8 +149,9 @@ def issued_mfma_flops(batch, frames):
     hdr = gcn_tables.STREAM_UMAX * gcn_tables.STREAM_REC
     tiles16 = batch * ((frames + 15) // 16)
     per_rec = 4 * 16 * 2048.0                       # one record = 16 MFMAs in each of the 4 channel phases
-    out = {'gcn2_forward': int(tables.stream_c[:, hdr].sum()) * per_rec * tiles16,
-           'gcn2_data_gradient': int(tables.stream_r[:, hdr].sum()) * per_rec * tiles16}
+    # (the statically scheduled kernel and the run-time work stream split long lists the same way: same step count)
+    out = {'gcn_forward': int(tables.stream_c[:, hdr].sum()) * per_rec * tiles16,
+           'gcn_data_gradient': int(tables.stream_r[:, hdr].sum()) * per_rec * tiles16}
     out.update(gcn_op.grad_kernel_mfma_flops(tables, batch, frames))
     out['tconv2_forward'] = out['tconv2_data_gradient'] = 3 * V * per_rec * tiles16
     out['tconv_weight_grad'] = 3 * 2.0 * 64 * 64 * batch * frames * V
@@ -176,23 +179,25 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
                 'tflops': round(tf, 2), 'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
 
     rows = {tag: row(tag) for tag in sorted(per) if tag in issued}
-    g2 = [t for t in ('gcn2_forward', 'gcn2_data_gradient') if t in per]
+    g2 = [t for t in ('gcn_forward', 'gcn_data_gradient') if t in per]
     n_g2 = sum(per[t][1] for t in g2)
     ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
     fl = sum(issued[t] * per[t][1] for t in g2) / n_g2
     tf = fl / ms / 1e9
-    traffic = _profile_json('r3_gcn2_pmc_traffic.json') or _profile_json('r2_gcn2_pmc_traffic.json')
+    traffic = _profile_json('r3_gcn3_pmc_traffic.json') or _profile_json('r2_gcn2_pmc_traffic.json')
     cols = batch_size * frames * 53
     scale = cols / float(32 * 1024 * 53)
-    roof = {'bound': 'mfma', 'kernel': 'gcn2_kernel (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
+    from pose2room_amd.p2rnet import gcn_op
+    kname = 'gcn3_kernel (statically scheduled)' if gcn_op.USE_GEN3 else 'gcn2_kernel'
+    roof = {'bound': 'mfma', 'kernel': kname + ' (ST-GCN graph conv: 6 forward + 6 data-gradient launches/step)',
             'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
             'traffic': int(traffic['bytes_per_launch'] * scale) if traffic else None,
             'ms_per_launch': round(ms, 4), 'timing': f'HIP events around each of the {n_g2 // steps} launches per step inside '
-                                                      f'{steps} instrumented train steps (includes the 2 us stream-fill pre-launch)',
+                                                      f'{steps} instrumented train steps',
             'flops_per_launch': fl, 'flops': 'MFMA FLOPs issued (454 of 583 (plane, joint) units forward, 369 data gradient)',
-            'ms_forward': round(per['gcn2_forward'][0], 4) if 'gcn2_forward' in per else None,
-            'ms_data_gradient': round(per['gcn2_data_gradient'][0], 4) if 'gcn2_data_gradient' in per else None,
+            'ms_forward': round(per['gcn_forward'][0], 4) if 'gcn_forward' in per else None,
+            'ms_data_gradient': round(per['gcn_data_gradient'][0], 4) if 'gcn_data_gradient' in per else None,
             'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
             'frac_dense_equivalent': round(dense / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
             'dense_equivalent': 'the operator with every (plane, joint) unit computed (the count rounds 1-2 quoted); '

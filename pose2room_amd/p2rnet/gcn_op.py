@@ -257,6 +257,10 @@ def grad_kernel_mfma_flops(tables, batch, frames):
         joints = sorted({c // F for c in range(16 * t, 16 * t + 16) if c < F * V})
         units += sum(int(live[k, joints].any()) for k in range(K)) if joints else 0
     dc = units * 64 * 2048.0 * batch * ((frames + F - 1) // F)
+    if USE_GEN3 and tables.gen3 and frames % 16 == 0:
+        # gcn3_dcoef_kernel: one 16-MFMA product per live (plane, joint) unit of the row lists, 16-frame tile and
+        # output-row phase (the rest of a long list reuses the product)
+        dc = int(live.sum()) * 4 * 16 * 2048.0 * batch * (frames // 16)
     return {'gcn_weight_grad': dw, 'gcn_coef_grad': dc}
 
 
