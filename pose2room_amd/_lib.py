@@ -65,3 +65,20 @@ def ptr(t):
 def current_stream(device):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def sum_leading(part, tr64=False):
+    """part [P, ...] f32 (kernel partials, one row per workgroup) -> part.sum(0), optionally with every trailing
+    64 x 64 block transposed; one streaming launch (csrc/bn_act.hip: p2r_sum_leading)."""
+    import torch
+    P = part.shape[0]
+    M = part.numel() // P
+    if not (part.is_cuda and part.dtype == torch.float32 and part.is_contiguous() and M % 4 == 0
+            and part.data_ptr() % 16 == 0):
+        out = part.sum(0)
+        return out.transpose(-1, -2).contiguous() if tr64 else out
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        check(lib().p2r_sum_leading(P, ctypes.c_longlong(M), ptr(part), ptr(out), int(bool(tr64)),
+                                    current_stream(part.device)), "sum_leading")
+    return out

@@ -430,3 +430,50 @@ extern "C" int p2r_colsum(int rows, int T, int V, const float *x, float *out_par
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
+
+// ---- sum of per-workgroup partials over the leading axis ---------------------------------------------------------
+// in [P][M] -> out [M] (or, tr64: M = G * 64 * 64 and every 64 x 64 block comes out transposed).  The weight- and
+// adjacency-gradient kernels leave one partial per persistent workgroup (P = 256; the graph-conv weight gradient is
+// 46 MB of them); a generic strided reduction reads that at a fraction of the HBM rate, this one streams it: a thread
+// owns four consecutive outputs (16-byte loads, eight rows in flight), rows are added in order (deterministic).
+namespace {
+__global__ __launch_bounds__(256) void sum_leading_kernel(int P, long long M4, const float4 *__restrict__ in,
+                                                          float *__restrict__ out, int tr64) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = 0;
+  for (; p + 8 <= P; p += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld_stream(reinterpret_cast<const float *>(in + (size_t)(p + u) * M4 + i));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; p < P; ++p) {
+    const float4 v = in[(size_t)p * M4 + i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (!tr64) {
+    reinterpret_cast<float4 *>(out)[i] = acc;
+  } else {
+    const long long e = 4 * i;                       // (block, a, b..b+3) -> (block, b.., a)
+    const long long blk = e >> 12;
+    const int a = (int)((e >> 6) & 63), b = (int)(e & 63);
+    float *o = out + (blk << 12) + a;
+    o[(b + 0) * 64] = acc.x; o[(b + 1) * 64] = acc.y; o[(b + 2) * 64] = acc.z; o[(b + 3) * 64] = acc.w;
+  }
+}
+}  // namespace
+
+extern "C" int p2r_sum_leading(int P, long long M, const float *in, float *out, int tr64, void *stream) {
+  if (P <= 0 || M <= 0 || (M % 4) != 0 || ((uintptr_t)in % 16) != 0 || ((uintptr_t)out % 16) != 0) return P2R_EINVAL;
+  if (tr64 && (M % 4096) != 0) return P2R_EINVAL;
+  const long long M4 = M / 4;
+  const long long blocks = (M4 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+  hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)blocks), dim3(256), 0, p2r_stream(stream), P, M4,
+                     reinterpret_cast<const float4 *>(in), out, tr64);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}

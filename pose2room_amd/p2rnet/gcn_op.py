@@ -207,9 +207,9 @@ class _GraphConv(Function):
                     N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(t['nbr_r']),
                     _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), 1, st),
                     "stgcn_gcn_weight_grad")
-                dW = part.sum(0).transpose(1, 2).reshape(K * C, C)
+                dW = _lib.sum_leading(part, tr64=True).reshape(K * C, C)      # the kernel returns dW_k^T
                 if bpart is not None:
-                    dbias = bpart.sum(0)                                   # (C, V)
+                    dbias = _lib.sum_leading(bpart)                        # (C, V)
             if ctx.needs_input_grad[3]:
                 # adjacency gradient in ROW-list form: Y_k = W_k . x on MFMA, reduced against dz gathered through
                 # the row lists (same kernel as the column form with the roles of x and dz swapped); the row lists
@@ -225,7 +225,7 @@ class _GraphConv(Function):
                     _lib.check(lib.p2r_stgcn_gcn_coef_grad(
                         N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(W), _lib.ptr(t['nbr_r']),
                         _lib.ptr(t['real_r']), _N_BLOCKS, _lib.ptr(part), st), "stgcn_gcn_coef_grad")
-                dcoef_r = part.sum(0)
+                dcoef_r = _lib.sum_leading(part)
         if ctx.needs_input_grad[4] and dbias is None:
             part = torch.empty((N * C, V), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):

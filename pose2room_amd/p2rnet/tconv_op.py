@@ -147,9 +147,9 @@ class _BNReLUTConv(Function):
             _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
                                                        _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
                        "stgcn_tconv_weight_grad")
-            dW = part.sum(0).view(ctx.wshape)      # the kernel writes its partials in the weight's own (c, ci, tap) order
+            dW = _lib.sum_leading(part).view(ctx.wshape)      # the kernel writes its partials in the weight's own (c, ci, tap) order
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
-                dbias = bpart.sum(0)
+                dbias = _lib.sum_leading(bpart)
         return dz, dgamma, dbeta, None, dW, dbias, None, None, None, None
 
 

@@ -58,7 +58,7 @@ def _weight_grad(dZ, X):
     with torch.cuda.device(dZ.device):
         _lib.check(_lib.lib().p2r_gemm_nt_256(B, L, _SPLIT, _lib.ptr(dZ), _lib.ptr(X), _lib.ptr(part),
                                               _lib.current_stream(dZ.device)), "gemm_nt_256")
-    return part.sum(0)
+    return _lib.sum_leading(part)
 
 
 class _SAVotes(Function):
