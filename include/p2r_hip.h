@@ -244,6 +244,19 @@ int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const
 int p2r_stgcn_gcn3_coef_grad(int N, int T, int V, int K, int ltot, const float *x, const float *dz,
                              const float *Wp, int n_blocks, float *dcoef_partial, void *stream);
 
+/* Weight gradient, statically scheduled like p2r_stgcn_gcn3_forward (csrc/stgcn_gcn3_dw.hip; requires
+ * p2r_stgcn_gcn3_signature(1) == signature of the caller's row tables):
+ *   dw_partial [n_blocks][K][64][64] = per-workgroup partial of dW_k TRANSPOSED ([k][ci][c]),
+ *   dW_k[c][ci] = sum over (n, t, v) of (sum_j a_k(v, w_j) dz[c, t, w_j]) * x[ci, t, v]
+ * (aggregation on the gradient side through the row lists; coef [ltot][53] = row coefficient table), summed over the
+ * leading axis and transposed by the caller (p2r_sum_leading, tr64).  colsum_partial (optional) [n_blocks][64][53] =
+ * per-workgroup sums of dz over samples and frames (gradient of the bias table).  T % 4 == 0, x and dz 16-byte
+ * aligned (P2R_EINVAL otherwise: use p2r_stgcn_gcn_weight_grad).  Replaces the autograd of the 1x1 conv weight
+ * (stgcn_layers.py:57-67). */
+int p2r_stgcn_gcn3_weight_grad(int N, int T, int V, int K, int ltot, const float *x, const float *dz,
+                               const float *coef, int n_blocks, float *dw_partial, float *colsum_partial,
+                               void *stream);
+
 /* weight gradient of the above (autograd of stgcn_layers.py:62-65): with G_k = x aggregated
  * through the lists of plane k, dw_partial [n_blocks][K][64][64] holds per-workgroup sums over
  * all columns of dz[a][col] * G_k[b][col] at [k][a][b], to be summed over the leading axis by the

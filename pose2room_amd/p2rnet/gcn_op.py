@@ -203,10 +203,16 @@ class _GraphConv(Function):
                 part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
                 # the bias-table gradient (column sums of dz) rides on the same pass over dz
                 bpart = torch.empty((_N_BLOCKS, C, V), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
-                _lib.check(lib.p2r_stgcn_gcn_weight_grad(
-                    N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(t['nbr_r']),
-                    _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), 1, st),
-                    "stgcn_gcn_weight_grad")
+                if USE_GEN3 and tables.gen3 and T % 4 == 0 and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0:
+                    # statically scheduled kernel (csrc/stgcn_gcn3_dw.hip)
+                    _lib.check(lib.p2r_stgcn_gcn3_weight_grad(
+                        N, T, V, K, coef_r.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(coef_r.contiguous()), _N_BLOCKS,
+                        _lib.ptr(part), _lib.ptr(bpart), st), "stgcn_gcn3_weight_grad")
+                else:
+                    _lib.check(lib.p2r_stgcn_gcn_weight_grad(
+                        N, T, V, K, tables.LkA_r, _lib.ptr(dz), _lib.ptr(x), _lib.ptr(t['nbr_r']),
+                        _lib.ptr(coef_r.contiguous()), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), 1, st),
+                        "stgcn_gcn_weight_grad")
                 dW = _lib.sum_leading(part, tr64=True).reshape(K * C, C)      # the kernel returns dW_k^T
                 if bpart is not None:
                     dbias = _lib.sum_leading(bpart)                        # (C, V)

@@ -143,6 +143,78 @@ def emit_coef_grad(nbr, gidx, Lk, out):
         out.append('')
 
 
+DW_SETS = ((1, 5), (0, 9), (3, 2, 4, 6), (7, 8, 10))      # plane sets of the weight-gradient kernel (see emit_weight_grad)
+DW_MAXNE = 12
+
+
+def emit_weight_grad(nbr, gidx, Lk, out):
+    """Weight-gradient kernel (gcn3_dw_kernel).  dW_k^T[ci][c] = sum over columns of X[ci][col] * V_k[c][col] with
+    V_k(v) = sum_j a_j dZ(w_j): one MFMA k-step = the 4 frames of a tile at ONE joint v, so the row list of a
+    (plane, joint) unit is wave-uniform and empty units are skipped exactly.  A wave owns a SET of planes and one half
+    of the 64 columns c (two 16-column n-tiles, built as packed pairs): 8 waves = 4 sets x 2 halves.  The sets are
+    balanced by live units -- (52+49, 53+46, 52+17+14+12, 49+12+13) for the P2RNet skeleton -- and dealt to the waves
+    so that the two waves of a SIMD (w, w + 4) carry 175 / 194 / 175 / 194 units.
+    Macros: W3_A(set, joint) loads the A operands (X at the joint, 4 m-tiles) of the joint whose steps come next into
+    register set `set`; W3_FIRST(ne, o.., c..) builds the first B pair; W3_STEP(aset, plane_slot, ne, o.., c..) =
+    gathers of the NEXT step, 8 MFMAs of this one, combine of the next; W3_LAST(aset, plane_slot)."""
+    gidx = np.asarray(gidx)
+    nbr = np.asarray(nbr)
+    V = gidx.shape[1]
+    K = len(Lk)
+    lofs = np.concatenate([[0], np.cumsum(Lk)])
+    length = np.zeros((K, V), dtype=np.int64)
+    for k in range(K):
+        length[k] = (gidx[lofs[k]:lofs[k + 1]] >= 0).sum(0)
+    assert sorted(k for s in DW_SETS for k in s) == list(range(K)), 'DW_SETS must partition the planes'
+    assert int(length.max()) <= DW_MAXNE
+    loads = [int(sum((length[k] > 0).sum() for k in s)) for s in DW_SETS]
+    # wave -> (set, half): waves w and w + 4 share a SIMD; heavy sets are paired with light ones
+    order = sorted(range(4), key=lambda i: -loads[i])               # heaviest .. lightest
+    pairs = [(order[0], order[3]), (order[3], order[0]), (order[1], order[2]), (order[2], order[1])]
+    wave_set = [None] * NW
+    for i, (a, b) in enumerate(pairs):
+        wave_set[i] = (a, 0)
+        wave_set[i + 4] = (b, 1)
+    out.append('// ---- weight gradient (row lists): plane sets %s, live units %s; wave -> (set, column half): %s'
+               % (DW_SETS, loads, wave_set))
+    out.append('#define W3_WAVE_SET {' + ', '.join(str(s) for s, _ in wave_set) + '}')
+    out.append('#define W3_WAVE_HALF {' + ', '.join(str(h) for _, h in wave_set) + '}')
+    out.append('#define W3_SET_PLANES {' + ', '.join('{' + ', '.join(str(k) for k in (list(s) + [-1] * 4)[:4]) + '}' for s in DW_SETS) + '}')
+    out.append('#define W3_MAXPL 4')
+    out.append('#define W3_LIGHT_SET %d' % order[3])
+    for si, planes in enumerate(DW_SETS):
+        steps = []                                     # (joint, plane slot, entries)
+        for v in range(V):
+            for slot, k in enumerate(planes):
+                L = int(length[k, v])
+                if L:
+                    steps.append((v, slot, [(int(nbr[lofs[k] + e, v]), int((lofs[k] + e) * V + v)) for e in range(L)]))
+        lines = []
+        joints = []
+        for v, _, _ in steps:
+            if not joints or joints[-1] != v:
+                joints.append(v)
+        aset = {v: i & 1 for i, v in enumerate(joints)}
+        lines.append('W3_A(%d, %d)' % (aset[joints[0]], joints[0]))
+        lines.append('W3_FIRST(%d, %s)' % (len(steps[0][2]), fmt_entries_n(steps[0][2], DW_MAXNE)))
+        for u, (v, slot, ent) in enumerate(steps):
+            nxt = steps[u + 1] if u + 1 < len(steps) else None
+            if nxt is not None and nxt[0] != v:        # the A operands of the next joint land under this step's MFMAs
+                lines.append('W3_A(%d, %d)' % (aset[nxt[0]], nxt[0]))
+            if nxt is not None:
+                lines.append('W3_STEP(%d, %d, %d, %s)' % (aset[v], slot, len(nxt[2]), fmt_entries_n(nxt[2], DW_MAXNE)))
+            else:
+                lines.append('W3_LAST(%d, %d)' % (aset[v], slot))
+        out.append(f'#define W3_BODY_{si} \\')
+        out.append(' \\\n'.join('  ' + l for l in lines))
+        out.append('')
+
+
+def fmt_entries_n(ent, n):
+    pad = list(ent) + [(0, -1)] * (n - len(ent))
+    return ', '.join('%d, %d' % (4 * j, ci) for j, ci in pad)
+
+
 def fmt_entries(ent):
     """Six (LDS byte offset of the source joint, coefficient-table index) pairs, padded with (0, -1)."""
     pad = list(ent) + [(0, -1)] * (CHUNK - len(ent))
@@ -171,6 +243,7 @@ def main():
         emit_form(form, nbr, gidx, Lk, out)
         if form == 1:
             emit_coef_grad(nbr, gidx, Lk, out)
+            emit_weight_grad(nbr, gidx, Lk, out)
     path = os.path.join(ROOT, 'pose2room_amd', 'csrc', 'gcn3_sched.inc')
     with open(path, 'w') as f:
         f.write('\n'.join(out) + '\n')
