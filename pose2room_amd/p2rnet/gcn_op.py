@@ -267,6 +267,9 @@ def grad_kernel_mfma_flops(tables, batch, frames):
         # gcn3_dcoef_kernel: one 16-MFMA product per live (plane, joint) unit of the row lists, 16-frame tile and
         # output-row phase (the rest of a long list reuses the product)
         dc = int(live.sum()) * 4 * 16 * 2048.0 * batch * (frames // 16)
+    if USE_GEN3 and tables.gen3 and frames % 4 == 0:
+        # gcn3_dw_kernel: 16 MFMAs (4 m x 4 n tiles, one k-step) per live (plane, joint) unit and 4-frame tile
+        dw = int(live.sum()) * 16 * 2048.0 * batch * (frames // 4)
     return {'gcn_weight_grad': dw, 'gcn_coef_grad': dc}
 
 
