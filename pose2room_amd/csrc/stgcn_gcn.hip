@@ -321,9 +321,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int DW_F = 4;
 constexpr int DW_MAXV = 64;
-#ifndef DW_SETS
 #define DW_SETS 4   // 16 waves = four per SIMD at 128 VGPRs: measured 1.45 ms vs 1.58 (12 waves) and 1.68 (8 waves)
-#endif
 constexpr int DW_PL = 12 / DW_SETS;   // planes per wave set (the sets cover up to 12 planes)
 constexpr int DW_THREADS = 64 * 4 * DW_SETS;
 constexpr int DW_NW = DW_THREADS / 64;
@@ -524,36 +522,17 @@ __global__ __launch_bounds__(DW_THREADS, DW_SETS == 2 ? 2 : 1) void gcn_dw_kerne
 #pragma unroll
         for (int f = 0; f < DW_F; ++f) b[f] = 0.f;
         // lists longer than six go in two passes: bounds the live gather registers (no scratch)
-#if DW_SETS == 2
-        if (Lr <= 1) dw_plane<1>(trow, V, xrow, V, live, Lr, b);
-        else if (Lr <= 3) dw_plane<3>(trow, V, xrow, V, live, Lr, b);
-        else if (Lr <= 6) dw_plane<6>(trow, V, xrow, V, live, Lr, b);
-        else {
-          dw_plane<6>(trow, V, xrow, V, live, 6, b);
-          if (Lr <= 9) dw_plane<3>(trow + 6 * V, V, xrow, V, live, Lr - 6, b);
-          else dw_plane<6>(trow + 6 * V, V, xrow, V, live, Lr - 6, b);
-        }
-#else
         // tighter register budget: passes of at most three list entries
-#ifndef DWX_NOGATHER
         for (int j0 = 0; j0 < Lr; j0 += 3) {
           const int rem = Lr - j0;
           if (rem <= 1) dw_plane<1>(trow + j0 * V, V, xrow, V, live, rem, b);
           else dw_plane<3>(trow + j0 * V, V, xrow, V, live, rem < 3 ? rem : 3, b);
         }
-#else
-        b[0] = b[1] = b[2] = b[3] = a[0][0];
-#endif
-#endif
-#ifndef DWX_NOMFMA
 #pragma unroll
         for (int f = 0; f < DW_F; ++f)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
             acc[kk][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f], b[f], acc[kk][m], 0, 0, 0);
-#else
-        acc[kk][0][0] += b[0] + b[1] + b[2] + b[3] + a[0][0] + a[1][1] + a[2][2] + a[3][3];
-#endif
 
       }
     }
@@ -764,16 +743,9 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
       fbase[i] = valid[i] ? f * p.V : 0;
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-#ifdef DCX_NOBZ
-        bz[i][s] = (float)(s + i);
-#else
         bz[i][s] = valid[i] ? dg[(size_t)(16 * g + s) * row_stride + fbase[i] + wj[i]] : 0.f;
-#endif
     }
     __syncthreads();
-#ifdef DCX_NOSTAGE
-    if (tile == (int)blockIdx.x)
-#endif
 #pragma unroll 1
     for (int rg = wave; rg < GC_C / 4; rg += DC_THREADS / 64) {       // row group = 4 consecutive rows
       float v[4][GC_NP / 64];
@@ -800,11 +772,7 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         const float4 *wp = reinterpret_cast<const float4 *>(Wt + ((size_t)k * GC_C + 16 * m + r) * GC_C + 16 * g);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#ifdef DCX_NOW
-          const float4 u = make_float4((float)k, (float)m, (float)q, 1.f);
-#else
           const float4 u = wp[q];
-#endif
           a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
         }
       }
@@ -820,15 +788,8 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
         for (int s = 0; s < 16; ++s)
 #pragma unroll
           for (int m = 0; m < 4; ++m)
-#ifndef DCX_NOMFMA
             h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bz[i][s], h[m], 0, 0, 0);
-#else
-            h[m][s & 3] += a[m][s] * bz[i][s & 1];
-#endif
         // h[m][q] = H_k[ci = 16m + 4g + q][col_i]
-#ifdef DCX_NOREDUCE
-        if (h[0][0] + h[1][1] + h[2][2] + h[3][3] == 123.456f) dcs[tid] = 1.f;
-#else
         if (valid[i]) {
           const int2 *trow = tbl + lofs * p.V + wj[i];
           float *drow = dcs + lofs * p.V + wj[i];
@@ -846,7 +807,6 @@ __global__ __launch_bounds__(DC_THREADS, 2) void gcn_dcoef_kernel(GcnParams p, i
             default: dc_reduce<12>(h, xs4, g, trow, p.V, fbase[i], drow, L); break;
           }
         }
-#endif
       }
     }
   }

@@ -285,10 +285,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
           if (nk == 15) load_a(plane0, (ph + 1) & (G2_NPH - 1));
           else load_a(nk, ph);
         }
-#ifndef G2X_NODMA
         if (copy && pieces < PW16) dma_piece(pieces, buf_nxt, src, svc);
         ++pieces;
-#endif
         bool started = false;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
@@ -298,58 +296,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
             // of them) read a third of the LDS words.  One MFMA block for both kinds keeps the accumulators in place.
             const bool short_rec = (__builtin_amdgcn_readfirstlane(n0.x) & 16) != 0;
             float xv[6][4];
-#ifndef G2X_NOGATHER
             if (short_rec) gather(NE2{}, n0, xl, xv);
             else gather(NE6{}, n0, xl, xv);
-#endif
-#ifdef G2X_SLOAD
-            // the record after next: requested HERE, ahead of the MFMA run (left to the compiler the scalar loads end
-            // up behind it, followed at once by the wait for them); consumed behind the run, after an explicit wait
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            i32x4 q0, q1, q2;
-            {
-              const int4 *rp = st + 3 * u + 6;
-              asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
-                           : "=&s"(q0), "=&s"(q1), "=&s"(q2) : "s"(rp) : "memory");
-            }
-#else
             const int4 m0 = st[3 * u + 6], m1 = st[3 * u + 7], m2 = st[3 * u + 8];
-#endif
             __builtin_amdgcn_sched_barrier(0);       // all LDS reads are requested before the MFMAs ...
-#ifndef G2X_NOMFMA
-#ifdef G2X_MFMAX
-#pragma unroll
-            for (int rep = 0; rep < G2X_MFMAX; ++rep)
-#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
               for (int m = 0; m < 4; ++m)
                 acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b_cur[s], acc[i][m], 0, 0, 0);
-#else
-            acc[i][0][0] += b_cur[0] + b_cur[1] + b_cur[2] + b_cur[3] + a[0][0];
-#endif
             __builtin_amdgcn_sched_barrier(0);       // ... and consumed after them: no s_waitcnt inside the MFMA run
-#ifdef G2X_SLOAD
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2) : : "memory");
-            const int4 m0 = make_int4(q0.x, q0.y, q0.z, q0.w), m1 = make_int4(q1.x, q1.y, q1.z, q1.w),
-                       m2 = make_int4(q2.x, q2.y, q2.z, q2.w);
-#endif
-#ifndef G2X_NOGATHER
             if (short_rec) combine(NE2{}, n1, n2, xv, b_cur);
             else combine(NE6{}, n1, n2, xv, b_cur);
-#else
-            b_cur[0] = b_cur[1] = b_cur[2] = b_cur[3] = __int_as_float(n1.x);
-#endif
             d = __builtin_amdgcn_readfirstlane(n0.x);
             n0 = m0; n1 = m1; n2 = m2;
             ++u;
           }
         }
       }
-#ifndef G2X_NODMA
       for (; copy && pieces < PW16; ++pieces) dma_piece(pieces, buf_nxt, src, svc);
-#endif
     }
 
     // ---- epilogue: D[row = 16 m + 4 g + q][frame r] of joint sj[i]; statistics of the stored values.
@@ -377,7 +342,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
           }
         }
     }
-#ifndef G2X_NOSTORE
     if (LAYOUT == 0 && p.vec && frames == G2_F) {
       // Full tiles leave through LDS: a (row, frame) line of the (N,C,T,V) tensor holds 16 consecutive joints, which
       // belong to several waves -- stored from the accumulators it would go out as 12/16-byte fragments (measured:
@@ -530,7 +494,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
           }
         }
     }
-#endif
   }
 
   if (stats_partial) {
@@ -544,14 +507,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gcn2_kernel(
   }
 }
 
-#ifdef G2X_NW16
-constexpr int G2_NW = 16, G2_SLOTS = 4;
-#else
 constexpr int G2_NW = 8, G2_SLOTS = 7;
-#endif
-#ifndef G2X_LAYOUT
-#define G2X_LAYOUT 0
-#endif
+constexpr int G2_LAYOUT = 0;          // LDS position of (frame, joint) inside a row: the tensor's own [frame][joint] order
 
 }  // namespace
 
@@ -602,14 +559,14 @@ extern "C" int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, cons
                      stream, coef, stream_work);
   P2R_LAUNCH_CHECK();
   if (bwd) {
-    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT, true>;
+    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2_LAYOUT, true>;
     static unsigned char lds_ok[P2R_MAX_DEVICES];
     hipError_t e = p2r_allow_big_lds(kern, lds_ok);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(G2_NW * 64), lds, p2r_stream(stream_h), p, x, Wp, stream_work, bias_cv,
                        addend, z, stats_partial, bwd_u, bwd_mask, bwd_fin);
   } else {
-    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2X_LAYOUT, false>;
+    auto kern = gcn2_kernel<G2_NW, G2_SLOTS, 53, G2_LAYOUT, false>;
     static unsigned char lds_ok[P2R_MAX_DEVICES];
     hipError_t e = p2r_allow_big_lds(kern, lds_ok);
     if (e != hipSuccess) return (int)e;

@@ -96,18 +96,6 @@ __device__ __forceinline__ f32x2 w3_combine(const f32x2 (&dv)[W3_MAXNE], const f
   constexpr int off_[W3_MAXNE] = {o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11};                                   \
   constexpr int ci_[W3_MAXNE] = {c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11};
 
-#ifdef W3X_NOGATHER
-#define W3X_GATHER(ne)
-#define W3X_COMBINE(ne)
-#else
-#define W3X_GATHER(ne) w3_gather_n<ne>(dl, cl, off_, ci_, dv_, cf_);
-#define W3X_COMBINE(ne) b_cur = w3_combine<ne>(dv_, cf_);
-#endif
-#ifdef W3X_MFMAX2
-#define W3X_MORE(slot, aset) w3_mfma8(acc[slot], aS[aset], b_cur);
-#else
-#define W3X_MORE(slot, aset)
-#endif
 #define W3_A(set, joint)                                                                            \
   {                                                                                                 \
     _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                \
@@ -124,12 +112,11 @@ __device__ __forceinline__ f32x2 w3_combine(const f32x2 (&dv)[W3_MAXNE], const f
   {                                                              \
     W3_UNPACK(__VA_ARGS__)                                       \
     f32x2 dv_[W3_MAXNE]; float cf_[W3_MAXNE];                    \
-    W3X_GATHER(ne)                                               \
+    w3_gather_n<ne>(dl, cl, off_, ci_, dv_, cf_);                \
     __builtin_amdgcn_sched_barrier(0);                           \
     w3_mfma8(acc[slot], aS[aset], b_cur);                        \
-    W3X_MORE(slot, aset)                                         \
     __builtin_amdgcn_sched_barrier(0);                           \
-    W3X_COMBINE(ne)                                              \
+    b_cur = w3_combine<ne>(dv_, cf_);                            \
   }
 #define W3_LAST(aset, slot)                \
   {                                        \
@@ -211,7 +198,6 @@ __device__ __forceinline__ void w3_wave_main(const W3Params &p, float *lds, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces have landed
     __syncthreads();                                       // ... everybody's
 
-#ifndef W3X_NOCOLSUM
     if (colsum_partial) {
       float dv4[W3_CS][4];
 #pragma unroll
@@ -221,15 +207,12 @@ __device__ __forceinline__ void w3_wave_main(const W3Params &p, float *lds, cons
 #pragma unroll
       for (int i = 0; i < W3_CS; ++i) cs[i] += (dv4[i][0] + dv4[i][1]) + (dv4[i][2] + dv4[i][3]);
     }
-#endif
     if constexpr (SET == 0) { W3_BODY_0 } else if constexpr (SET == 1) { W3_BODY_1 }
     else if constexpr (SET == 2) { W3_BODY_2 } else { W3_BODY_3 }
 
     __syncthreads();                                       // nobody reads the tiles any more
     const int ntile = tile + gridDim.x;
-#ifndef W3X_NODMA
     if (ntile < p.total_tiles) copy_tile(ntile);
-#endif
   }
 
   if (colsum_partial) {

@@ -118,12 +118,8 @@ __device__ __forceinline__ float d3_add_dpp(float v) {      // bound_ctrl: lanes
 // no branch.  The code around it is wave-uniform, so exec is all ones before and after.
 template <int OFF>
 __device__ __forceinline__ void d3_lane_add(unsigned base, float v, unsigned long long mask) {
-#ifndef D3X_NOADD
   asm volatile("s_mov_b64 exec, %2\n\tds_add_f32 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
                : : "v"(base), "v"(v), "s"(mask), "n"(OFF) : "memory");
-#else
-  asm volatile("" : : "v"(base), "v"(v), "s"(mask));
-#endif
 }
 template <int NE, int C0, int C1, int C2, int C3, int C4, int C5>
 __device__ __forceinline__ void d3_reduce(const f32x4 &h, const float (&dv)[6][4], unsigned dcs) {
@@ -163,11 +159,6 @@ __device__ __forceinline__ void d3_reduce(const f32x4 &h, const float (&dv)[6][4
   if (NE == 5) d3_lane_add<4 * C4>(dcs, v[2], L63);
 }
 
-#ifdef D3X_NOREDUCE
-#define D3X_REDUCE(ne, c0, c1, c2, c3, c4, c5) asm volatile("" : : "v"(h), "v"(dv_[0][0]), "v"(dv_[ne - 1][3]));
-#else
-#define D3X_REDUCE(ne, c0, c1, c2, c3, c4, c5) d3_reduce<ne, c0, c1, c2, c3, c4, c5>(h, dv_, dcs_off);
-#endif
 #define D3_VISIT(set, plane, next, wrap, piece)                                      \
   {                                                                                  \
     load_a(aS[(set) ^ 1], next, (wrap) ? ((ph + 1) & 3) : ph);                        \
@@ -180,7 +171,7 @@ __device__ __forceinline__ void d3_reduce(const f32x4 &h, const float (&dv)[6][4
     __builtin_amdgcn_sched_barrier(0);                                           \
     d3_mfma16(h, aS[set], bz[slot]);                                             \
     __builtin_amdgcn_sched_barrier(0);                                           \
-    D3X_REDUCE(ne, c0, c1, c2, c3, c4, c5)                                       \
+    d3_reduce<ne, c0, c1, c2, c3, c4, c5>(h, dv_, dcs_off);                      \
   }
 #define D3_CONT(ne, o0, c0, o1, c1, o2, c2, o3, c3, o4, c4, o5, c5)   \
   {                                                                   \
@@ -267,9 +258,6 @@ __device__ __forceinline__ void d3_wave_main(const D3Params &p, float *lds, cons
       constexpr int na = (sj[0] >= 0) + (sj[1] >= 0) + (sj[2] >= 0) + (sj[3] >= 0);
       constexpr int nb = (sj[4] >= 0) + (sj[5] >= 0) + (sj[6] >= 0);
       static_assert(na >= 3 && nb == 3, "joint runs of the generated schedule");
-#ifdef D3X_NOBLOAD
-      if (tile == (int)blockIdx.x)
-#endif
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const float *row = xg + (size_t)4 * kk * row_stride;

@@ -93,12 +93,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       }
     }
     __syncthreads();
-#ifndef TWX_NOLOAD
     if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
-#endif
-#ifdef TWX_NOMFMA
-    continue;
-#endif
 
     int colv[TC_NT], base[TC_NT];
     bool valid[TC_NT];
@@ -182,9 +177,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
 // persistent grid; wave = (ci tile nt = wave&3, row group mh = wave>>2): TAPS planes x TW_MT row
 // tiles of accumulators; reduction steps of 4 consecutive columns.
 constexpr int TW_F = 4;
-#ifndef TW_WAVES
 #define TW_WAVES 16   // four waves per SIMD: same time as 8 for the 3-tap form, -15 % for the single-tap form
-#endif
 constexpr int TW_THREADS = 64 * TW_WAVES;
 constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves = 4 ci tiles x TW_WAVES/4 row groups)
 
@@ -258,9 +251,6 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   if (tile < total_tiles) issue_loads(tile);
   for (; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();                                   // previous tile fully consumed
-#ifdef TWX_NOSTAGE
-    if (tile == (int)blockIdx.x)
-#endif
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
       const int c = wave + hh * (TW_THREADS / 64);

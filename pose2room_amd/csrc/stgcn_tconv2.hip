@@ -32,7 +32,6 @@ constexpr int T2_CP = 16;           // channels per phase
 constexpr int T2_NPH = 4;
 constexpr int T2_NW = 8;            // waves per workgroup
 constexpr int T2_SLOTS = 7;         // joints per wave (consecutive)
-constexpr int T2_MAXTAPS = 3;
 
 struct T2Params {
   int T, tiles_per_seq, total_tiles;

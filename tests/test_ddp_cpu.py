@@ -88,7 +88,8 @@ def _single_process_average():
     from oracle.cpu_backend import cpu_ops
     from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
     from pose2room_amd.p2rnet.synthetic import make_batch
-    torch.set_num_threads(2)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(2)                      # as the two ranks (restored below: later tests in this process)
     cfg = P2RConfig(default_config('train', data={'num_frames': 32}), device='cpu')
     torch.manual_seed(42)
     net = METHODS.get('P2RNet')(cfg)
@@ -105,4 +106,5 @@ def _single_process_average():
                     total[k] = total.get(k, 0) + p.grad.detach().clone() / 2
             for k, v in loss.items():
                 losses[k] = losses.get(k, 0.0) + float(v.detach()) / 2
+    torch.set_num_threads(prev_threads)
     return total, losses
