@@ -370,6 +370,13 @@ int p2r_stgcn_tconv2_forward(int N, int T, int V, int taps, const float *x, cons
                              const float *Wp, const float *bias, float *out, float *stats_partial,
                              int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
 
+/* Third generation of the same operator (csrc/stgcn_tconv3.hip): per-wave straight-line programs, in-place MFMA
+ * blocks, precomputed DMA piece offsets (the recipe of p2r_stgcn_gcn3_forward).  Same arguments and results; requires
+ * T % 16 == 0 and x, out, bwd_z 16-byte aligned (P2R_EINVAL otherwise: use p2r_stgcn_tconv2_forward). */
+int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
+                             const float *Wp, const float *bias, float *out, float *stats_partial,
+                             int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
+
 /* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
 
 /* pos_embed[0] / sk_feat[0] (stgcn.py:46-63): x (N,3,L), W [64][3], bias [64] or NULL ->

@@ -1,0 +1,431 @@
+// stgcn_tconv3.hip -- temporal (3,1) / pointwise convolution of st_gcn_block fused with the preceding BatchNorm + ReLU,
+// third generation (statically scheduled), gfx950.
+//
+// Same operator and data movement as stgcn_tconv2.hip (reference models/p2rnet/modules/stgcn_layers.py:399-411 and its
+// data gradient):
+//     out[n,c,t,w] = bias[c] + sum_{p<TAPS} sum_ci W[p][c][ci] * h[n,ci,t+p-(TAPS-1)/2,w],  h = relu(x*scale+shift) or x
+// rebuilt the way stgcn_gcn3.hip rebuilt the graph convolution: every wave runs its own straight-line program (its
+// joints are ds_read immediates, the taps are unrolled, the A-operand sets ping-pong by name, the DMA pieces have
+// precomputed per-lane offsets and fixed places), the 16 MFMAs of a (tap, joint) unit are one assembly block that
+// accumulates in place, and the waves of a workgroup never share code between the first instruction and the last.
+// The second generation paid for the opposite on every count: the compiler renamed the accumulators along the MFMA
+// chains and reconciled them through scratch when the tap loop was unrolled (tried in round 3: 100 spilled VGPRs), the
+// piece offsets were recomputed with 64-bit multiplies per piece, and the pieces of the next slice, spread over the
+// three tap visits of a 4.6 us phase, were still in flight at the phase's end.
+//
+// Full tiles of 16-byte aligned rows only (T % 16 == 0): anything else runs on stgcn_tconv2.hip.
+#include "p2r_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T3_F = 16, T3_CP = 16, T3_NPH = 4, T3_NW = 8, T3_SLOTS = 7, T3_V = 53;
+constexpr int T3_RS = T3_F * T3_V;                  // 848
+constexpr int T3_MAIN = T3_CP * T3_RS;              // floats of the 16-frame part of a slice
+constexpr int T3_HRS = 2 * T3_V;                    // halo row: frame t0-1, frame t0+16
+constexpr int T3_HALO = T3_CP * T3_HRS;
+constexpr int T3_BUF = T3_MAIN + T3_HALO;           // floats per phase buffer (61,056 bytes)
+constexpr int T3_NV4 = T3_MAIN / 4;
+constexpr int T3_PIECES16 = (T3_NV4 + 63) / 64;     // 53
+constexpr int T3_PW16 = (T3_PIECES16 + T3_NW - 1) / T3_NW;     // 7 per wave
+constexpr int T3_PIECESH = (T3_HALO + 63) / 64;     // 27
+constexpr int T3_PWH = (T3_PIECESH + T3_NW - 1) / T3_NW;       // 4 per wave
+
+struct T3Params {
+  int T, tiles_per_seq, total_tiles;
+};
+
+__device__ __forceinline__ unsigned t3_lds_addr(const float *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+__device__ __forceinline__ void t3_dma16(const float *base, unsigned voff, float *lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(t3_lds_addr(lds_dst));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void t3_dma4(const float *base, unsigned voff, float *lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(t3_lds_addr(lds_dst));
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+// the 16 MFMAs of one (tap, joint) unit, accumulating in place (see stgcn_gcn3.hip)
+__device__ __forceinline__ void t3_mfma16(f32x4 (&acc)[4], const float (&a)[4][4], const float (&b)[4]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %4, %20, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %20, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, %12, %20, %2\n\tv_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %5, %21, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %21, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, %13, %21, %2\n\tv_mfma_f32_16x16x4_f32 %3, %17, %21, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %6, %22, %0\n\tv_mfma_f32_16x16x4_f32 %1, %10, %22, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, %14, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %18, %22, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %7, %23, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %23, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, %15, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %19, %23, %3"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+      : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]),
+        "v"(a[2][0]), "v"(a[2][1]), "v"(a[2][2]), "v"(a[2][3]), "v"(a[3][0]), "v"(a[3][1]), "v"(a[3][2]), "v"(a[3][3]),
+        "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+
+// XFORM: input transform relu(x * scale + shift) applied in place to each slice; BWD (data-gradient instance): the
+// statistics epilogue emits the two sums of the BatchNorm + ReLU backward of the layer in front (see stgcn_tconv2.hip).
+template <bool XFORM, bool BWD, int TAPS, int WAVE>
+__device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, const float *__restrict__ x,
+                                             const float *__restrict__ Wp, float *__restrict__ out, bool want_stats,
+                                             const float *__restrict__ bwd_z) {
+  constexpr int V = T3_V, NW = T3_NW, SLOTS = T3_SLOTS, RS = T3_RS, MAIN = T3_MAIN, HRS = T3_HRS, HALO = T3_HALO,
+                BUF = T3_BUF, NV4 = T3_NV4;
+  constexpr int wave = WAVE;
+  // joints of this wave: consecutive runs 7,7,7,7,7,6,6,6 (waves w and w + 4 share a SIMD: 14,13,13,13 units per tap)
+  constexpr int j0 = WAVE < 5 ? 7 * WAVE : 35 + 6 * (WAVE - 5);
+  constexpr int nslots = WAVE < 5 ? 7 : 6;
+  constexpr int PW16 = T3_PW16, PWH = TAPS > 1 ? T3_PWH : 0;
+  float *rowstat = lds + 2 * BUF;                     // [NW][64][2]
+  float *aff = rowstat + NW * 128;                    // [64][2] (scale, shift) of the input transform
+  float *bias_l = aff + 128;                          // [64]
+  float *bstat = bias_l + 64;                         // [64][2] (mean, invstd) of the BWD epilogue
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int g = lane >> 4, r = lane & 15;
+  const size_t row_stride = (size_t)p.T * V;
+  const float fillv = XFORM ? __int_as_float(0x7fc00000) : 0.f;   // outside the sequence: NaN -> relu gives the zero padding
+
+  // lane's read position inside a buffer for (tap, k-step s): channel 4s+g, frame r+tap-(TAPS-1)/2, the wave's first
+  // joint (halo rows for frames -1 / 16); the slot's joint is an immediate
+  unsigned rd[TAPS][4];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) {
+    const int f = r + tp - (TAPS - 1) / 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ch = 4 * s + g;
+      rd[tp][s] = (unsigned)((f < 0 ? MAIN + ch * HRS : (f >= T3_F ? MAIN + ch * HRS + V : ch * RS + f * V)) + j0) * 4u;
+    }
+  }
+
+  // this wave's DMA pieces of a slice; offsets relative to (channel row 0 of the slice, frame t0 - 1)
+  unsigned moff[PW16], hoff[PWH > 0 ? PWH : 1];
+  unsigned hmask = 0;                                 // bit i: this lane's element of halo piece i is frame t0+16 (else t0-1)
+#pragma unroll
+  for (int i = 0; i < PW16; ++i) {
+    const int pc = i * NW + wave, e = pc * 64 + lane;
+    const int row = e / (RS / 4), c4 = e - row * (RS / 4);
+    moff[i] = (pc < T3_PIECES16 && e < NV4) ? (unsigned)(((size_t)row * row_stride + V + 4 * c4) * sizeof(float)) : 0xffffffffu;
+  }
+#pragma unroll
+  for (int i = 0; i < PWH; ++i) {
+    const int pc = i * NW + wave, e = pc * 64 + lane;
+    const int row = e / HRS, q = e - row * HRS;
+    const int h = q >= V ? 1 : 0, v = q - h * V;
+    hoff[i] = (pc < T3_PIECESH && e < HALO) ? (unsigned)(((size_t)row * row_stride + (h ? RS + V : 0) + v) * sizeof(float)) : 0xffffffffu;
+    hmask |= (unsigned)h << i;
+  }
+  // base = address of (channel row 0 of the slice, frame t0 - 1); lo / hi: frame t0-1 / t0+16 exists in the sequence
+  auto copy_slice = [&](float *buf, const float *base, bool lo, bool hi) {
+#pragma unroll
+    for (int i = 0; i < PW16; ++i)
+      if (moff[i] != 0xffffffffu) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
+#pragma unroll
+    for (int i = 0; i < PWH; ++i)
+      if (hoff[i] != 0xffffffffu) {
+        const bool in = ((hmask >> i) & 1u) ? hi : lo;
+        if (in) t3_dma4(base, hoff[i], buf + MAIN + (i * NW + wave) * 64);
+        else buf[MAIN + (i * NW + wave) * 64 + lane] = fillv;
+      }
+  };
+
+  f32x4 acc[SLOTS][4];
+  float aS[2][4][4];
+  auto load_a = [&](float (&a)[4][4], int tp, int ph) {
+    const float4 *wp = reinterpret_cast<const float4 *>(Wp) + ((size_t)(tp * T3_NPH + ph) * 4) * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float4 u = wp[m * 64];
+      a[m][0] = u.x; a[m][1] = u.y; a[m][2] = u.z; a[m][3] = u.w;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.total_tiles) {       // prologue: phase 0 of the first tile
+    const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * T3_F;
+    copy_slice(lds, x + (size_t)seq * 64 * row_stride + (size_t)t0 * V - V, t0 > 0, t0 + T3_F < p.T);
+  }
+  load_a(aS[0], 0, 0);
+
+  for (; tile < p.total_tiles; tile += gridDim.x) {
+    const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * T3_F;
+    const float *xg = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
+    float *og = out + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
+    const float *zg = BWD ? bwd_z + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
+    const int ntile = tile + gridDim.x;
+    const bool has_next = ntile < p.total_tiles;
+    const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * T3_F : 0;
+    const float *nxg = x + (size_t)nseq * 64 * row_stride + (size_t)nt0 * V;
+
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][m][q] = bias_l[16 * m + 4 * g + q];
+
+#pragma unroll 1
+    for (int ph = 0; ph < T3_NPH; ++ph) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces of slice `ph` have landed
+      __syncthreads();                                      // ... everybody's; and nobody reads the other buffer any more
+      float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
+      const bool copy = ph + 1 < T3_NPH || has_next;
+      const bool same = ph + 1 < T3_NPH;
+      const float *src = (same ? xg + (size_t)(ph + 1) * T3_CP * row_stride : nxg) - V;
+      const bool slo = same ? t0 > 0 : nt0 > 0, shi = same ? t0 + T3_F < p.T : nt0 + T3_F < p.T;
+      if (XFORM) {
+        // BatchNorm affine + ReLU once per element, in place in the slice that has just landed
+        float *cur = lds + (ph & 1) * BUF;
+        float4 *cur4 = reinterpret_cast<float4 *>(cur);
+#pragma unroll
+        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+          const int e = it * NW * 64 + tid;
+          if (e < NV4) {
+            const int ch = T3_CP * ph + e / (RS / 4);
+            const float sc = aff[2 * ch], sh = aff[2 * ch + 1];
+            float4 v = cur4[e];
+            v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+            cur4[e] = v;
+          }
+        }
+        if (TAPS > 1)
+          for (int e = tid; e < HALO; e += NW * 64) {
+            const int ch = T3_CP * ph + e / HRS;
+            cur[MAIN + e] = fmaxf(fmaf(cur[MAIN + e], aff[2 * ch], aff[2 * ch + 1]), 0.f);
+          }
+        __syncthreads();
+      }
+
+      const char *bufc = reinterpret_cast<const char *>(lds + (ph & 1) * BUF);
+      float b_cur[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b_cur[s] = *reinterpret_cast<const float *>(bufc + rd[0][s]);
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp) {
+        {   // A operands of the next (tap, phase) into the other set; every piece of the next slice in the first visit
+          int ntp = tp + 1, nph = ph;
+          if (ntp == TAPS) { ntp = 0; nph = (ph + 1) & (T3_NPH - 1); }
+          load_a(aS[(tp & 1) ^ 1], ntp, nph);
+        }
+        if (tp == 0 && copy) copy_slice(buf_nxt, src, slo, shi);
+#pragma unroll
+        for (int i = 0; i < nslots; ++i) {
+          // B operand of the next unit requested before this unit's MFMAs
+          const int ni = i + 1 < nslots ? i + 1 : 0, ntp2 = i + 1 < nslots ? tp : tp + 1;
+          float b_nxt[4];
+          if (ntp2 < TAPS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b_nxt[s] = *reinterpret_cast<const float *>(bufc + rd[ntp2][s] + 4 * ni);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          t3_mfma16(acc[i], aS[tp & 1], b_cur);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ntp2 < TAPS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b_cur[s] = b_nxt[s];
+          }
+        }
+      }
+      if (TAPS & 1) {       // odd number of visits: the prefetched operands of the next phase sit in set 1
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) aS[0][m][s] = aS[1][m][s];
+      }
+    }
+
+    // ---- epilogue: statistics of the tile, then the tile itself through LDS as whole rows ------------------------
+    float *rs = rowstat + wave * 128;
+    if (!BWD && want_stats) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < nslots; ++i) {
+            const float v = acc[i][m][q];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
+          s1 = p2r_row16_sum(s1);
+          s2 = p2r_row16_sum(s2);
+          if (r == 0) {
+            rs[2 * (16 * m + 4 * g + q)] += s1;
+            rs[2 * (16 * m + 4 * g + q) + 1] += s2;
+          }
+        }
+    }
+    {
+      float *stg = lds + ((T3_NPH - 1) & 1) * BUF;          // main part of the last phase's buffer: free now
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int i = 0; i < nslots; ++i) {
+          float *d0 = stg + 4 * g * RS + r * V + j0 + i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
+        }
+        constexpr int R4 = RS / 4;                          // float4 per row (212)
+        constexpr int RIT = (R4 + 63) / 64;                 // 4
+        float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
+        if (BWD) {   // the saved activation of this wave's two rows: in flight across the staging barrier
+          const float4 *z4 = reinterpret_cast<const float4 *>(zg + (size_t)(16 * m + 2 * wave) * row_stride);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              zv[rr][it] = c4 < R4 ? z4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float4 *orow = reinterpret_cast<float4 *>(og + (size_t)16 * m * row_stride);
+        const float4 *srow = reinterpret_cast<const float4 *>(stg);
+        if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, c = 16 * m + row;
+            const float sc = aff[2 * c], sh = aff[2 * c + 1], mu = bstat[2 * c], is = bstat[2 * c + 1];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+              const int c4 = it * 64 + lane;
+              if (c4 < R4) {
+                const float4 v = srow[row * R4 + c4];
+                orow[(size_t)row * (row_stride / 4) + c4] = v;
+                const float4 zz = zv[rr][it];
+                const float g0 = fmaf(zz.x, sc, sh) > 0.f ? v.x : 0.f, g1 = fmaf(zz.y, sc, sh) > 0.f ? v.y : 0.f;
+                const float g2 = fmaf(zz.z, sc, sh) > 0.f ? v.z : 0.f, g3 = fmaf(zz.w, sc, sh) > 0.f ? v.w : 0.f;
+                s1 += (g0 + g1) + (g2 + g3);
+                s2 = fmaf(g0, (zz.x - mu) * is, s2); s2 = fmaf(g1, (zz.y - mu) * is, s2);
+                s2 = fmaf(g2, (zz.z - mu) * is, s2); s2 = fmaf(g3, (zz.w - mu) * is, s2);
+              }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              s1 += __shfl_xor(s1, off, 64);
+              s2 += __shfl_xor(s2, off, 64);
+            }
+            if (lane == 0) {
+              rs[2 * c] += s1;
+              rs[2 * c + 1] += s2;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+            const int e = it * NW * 64 + tid;
+            if (e < NV4) {
+              const int row = e / (RS / 4), c4 = e - row * (RS / 4);
+              orow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+}
+
+template <bool XFORM, bool BWD, int TAPS>
+__global__ __launch_bounds__(T3_NW * 64, 2) void tconv3_kernel(
+    T3Params p, const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
+    float *__restrict__ stats_partial, const float *__restrict__ bwd_z, const float *__restrict__ bwd_fin) {
+  constexpr int NW = T3_NW;
+  extern __shared__ float lds[];
+  float *rowstat = lds + 2 * T3_BUF;
+  float *aff = rowstat + NW * 128;
+  float *bias_l = aff + 128;
+  float *bstat = bias_l + 64;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
+  if (tid < 64) {
+    aff[2 * tid] = XFORM ? scale[tid] : (BWD ? bwd_fin[128 + tid] : 1.f);
+    aff[2 * tid + 1] = XFORM ? shift[tid] : (BWD ? bwd_fin[192 + tid] : 0.f);
+    bias_l[tid] = bias ? bias[tid] : 0.f;
+    bstat[2 * tid] = BWD ? bwd_fin[tid] : 0.f;
+    bstat[2 * tid + 1] = BWD ? bwd_fin[64 + tid] : 1.f;
+  }
+  __syncthreads();
+  const bool want_stats = stats_partial != nullptr;
+  switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+    case 0: t3_wave_main<XFORM, BWD, TAPS, 0>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 1: t3_wave_main<XFORM, BWD, TAPS, 1>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 2: t3_wave_main<XFORM, BWD, TAPS, 2>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 3: t3_wave_main<XFORM, BWD, TAPS, 3>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 4: t3_wave_main<XFORM, BWD, TAPS, 4>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 5: t3_wave_main<XFORM, BWD, TAPS, 5>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 6: t3_wave_main<XFORM, BWD, TAPS, 6>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    default: t3_wave_main<XFORM, BWD, TAPS, 7>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+  }
+  if (stats_partial) {
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += rowstat[w * 128 + tid];
+      stats_partial[(size_t)blockIdx.x * 128 + tid] = t;
+    }
+  }
+}
+
+template <bool XFORM, bool BWD, int TAPS>
+int tconv3_launch(const T3Params &p, int blocks, size_t lds, const float *x, const float *scale, const float *shift,
+                  const float *Wp, const float *bias, float *out, float *stats_partial, const float *bwd_z,
+                  const float *bwd_fin, void *stream) {
+  auto kern = tconv3_kernel<XFORM, BWD, TAPS>;
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(kern, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(T3_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
+                     stats_partial, bwd_z, bwd_fin);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+}  // namespace
+
+// Arguments and semantics of p2r_stgcn_tconv2_forward; additionally T % 16 == 0 and x, out (and bwd_z) 16-byte aligned
+// (P2R_EINVAL otherwise: the caller uses p2r_stgcn_tconv2_forward).
+extern "C" int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
+                                        const float *Wp, const float *bias, float *out, float *stats_partial,
+                                        int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream) {
+  if (N < 0 || T <= 0 || V != T3_V || (taps != 1 && taps != 3) || (scale == nullptr) != (shift == nullptr)) return P2R_EINVAL;
+  if ((bwd_z == nullptr) != (bwd_fin == nullptr) || (bwd_z && (scale || !stats_partial))) return P2R_EINVAL;
+  if (T % T3_F != 0 || T > (1 << 20) || ((uintptr_t)x % 16) != 0 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)bwd_z % 16) != 0)
+    return P2R_EINVAL;
+  if (n_partials) *n_partials = 0;
+  if (N == 0) return P2R_OK;
+  T3Params p;
+  p.T = T;
+  p.tiles_per_seq = T / T3_F;
+  const long long tiles = (long long)N * p.tiles_per_seq;
+  if (tiles > 0x7fffffffLL) return P2R_EINVAL;
+  p.total_tiles = (int)tiles;
+  const int blocks = (int)(tiles < 256 ? tiles : 256);
+  if (n_partials) *n_partials = blocks;
+  if (!out) return P2R_OK;
+  const size_t lds = (size_t)2 * T3_BUF * sizeof(float) + (size_t)T3_NW * 128 * sizeof(float) +
+                     (size_t)(128 + 64 + 128) * sizeof(float);
+#define P2R_T3(XF, BW) (taps == 3 ? tconv3_launch<XF, BW, 3>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream) \
+                                   : tconv3_launch<XF, BW, 1>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream))
+  if (bwd_z) return P2R_T3(false, true);
+  if (scale) return P2R_T3(true, false);
+  return P2R_T3(false, false);
+#undef P2R_T3
+}

@@ -20,6 +20,7 @@ from .. import _lib
 from . import bn_op
 
 _N_BLOCKS = 256
+USE_GEN3 = True      # statically scheduled kernel (csrc/stgcn_tconv3.hip); tests switch it off to reach tconv2
 
 
 def _permute_taps(W3):
@@ -48,10 +49,13 @@ def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
             st = _lib.current_stream(x.device)
             if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
                 part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
-            _lib.check(lib.p2r_stgcn_tconv2_forward(N, T, V, Wp.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
-                                                    _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None,
-                                                    _lib.ptr(bz), _lib.ptr(bfin), st),
-                       "stgcn_tconv2_forward")
+            # full tiles of aligned rows: the statically scheduled third generation; anything else the second
+            gen3 = (USE_GEN3 and T % 16 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
+                    and (bz is None or bz.data_ptr() % 16 == 0))
+            fn = lib.p2r_stgcn_tconv3_forward if gen3 else lib.p2r_stgcn_tconv2_forward
+            _lib.check(fn(N, T, V, Wp.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
+                          _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None, _lib.ptr(bz), _lib.ptr(bfin), st),
+                       "stgcn_tconv3_forward" if gen3 else "stgcn_tconv2_forward")
         return (out, part) if want_stats else out
     assert bwd is None
     with torch.cuda.device(x.device):

@@ -7,7 +7,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 53), (3, 9, 53), (2, 130, 53), (2, 17, 25), (5, 1000, 53), (2, 64, 53)])
+# T % 16 == 0 with 53 joints: the statically scheduled third generation (csrc/stgcn_tconv3.hip); (5, 1008): more tiles
+# than persistent workgroups; everything else: second generation / first generation (other joint counts)
+@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 53), (3, 9, 53), (2, 130, 53), (2, 17, 25), (5, 1000, 53), (2, 64, 53), (1, 16, 53),
+                                   (5, 1008, 53)])
 @pytest.mark.parametrize("train", [True, False])
 def test_bn_relu_tconv(dev, N, T, V, train):
     from pose2room_amd.p2rnet import tconv_op
@@ -57,7 +60,7 @@ def test_bn_relu_tconv(dev, N, T, V, train):
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
 
-@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 20), (3, 9, 20), (2, 130, 53), (2, 17, 64)])
+@pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 20), (3, 9, 20), (2, 130, 53), (2, 17, 64), (2, 48, 53), (3, 160, 53)])
 @pytest.mark.parametrize("train", [True, False])
 def test_bn_relu_pointwise(dev, N, T, V, train):
     """Single-tap form: BatchNorm1d -> ReLU -> Conv1d(64, 64, 1) of the embedding MLPs (stgcn.py:46-63)."""
@@ -137,3 +140,35 @@ def test_kernel_emitted_statistics(dev, N, T, V, taps):
     o = out.double()
     torch.testing.assert_close(mean, o.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(var, o.var(dim=(0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,T,taps", [(1, 16, 3), (3, 64, 3), (9, 480, 3), (2, 32, 1), (5, 1008, 1)])
+def test_tconv3_equals_tconv2(dev, N, T, taps):
+    """The statically scheduled kernel (csrc/stgcn_tconv3.hip) and the second generation run the same MFMA chain per
+    output element: bit-identical outputs and epilogue sums -- forward with the input transform and statistics, data
+    gradient, data gradient with the BatchNorm-backward epilogue; three taps and the single-tap form."""
+    from pose2room_amd.p2rnet import tconv_op
+    V = 53
+    g = torch.Generator().manual_seed(N * 13 + T + taps)
+    x = torch.randn(N, 64, T, V, generator=g).to(dev)
+    z = torch.randn(N, 64, T, V, generator=g).to(dev)
+    scale, shift = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+    bias = torch.randn(64, generator=g).to(dev)
+    fin = torch.randn(4, 64, generator=g).to(dev)
+    W3 = (torch.randn(taps, 64, 64, generator=g) / 8).to(dev)
+    cases = [dict(scale=scale, shift=shift, bias=bias, want_stats=True), dict(scale=None, shift=None, bias=None),
+             dict(scale=None, shift=None, bias=None, want_stats=True, bwd=(z, fin))]
+    try:
+        for kw in cases:
+            outs = []
+            for gen3 in (False, True):
+                tconv_op.USE_GEN3 = gen3
+                outs.append(tconv_op._tconv(x, kw['scale'], kw['shift'], W3, kw['bias'], kw.get('want_stats', False), kw.get('bwd')))
+            torch.cuda.synchronize()
+            a, b = outs
+            if isinstance(a, tuple):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1].sum(0), b[1].sum(0))
+            else:
+                assert torch.equal(a, b)
+    finally:
+        tconv_op.USE_GEN3 = True
