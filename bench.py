@@ -131,7 +131,8 @@ _TIMED = {
     'p2r_stgcn_gcn2_forward': lambda a: None if _null(a[12]) else ('gcn_data_gradient' if _null(a[10]) else 'gcn_forward'),
     'p2r_stgcn_gcn_weight_grad': lambda a: None if _null(a[10]) else 'gcn_weight_grad',
     'p2r_stgcn_gcn_coef_grad': lambda a: 'gcn_coef_grad',
-    'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv2_data_gradient' if _null(a[5]) else 'tconv2_forward'),
+    'p2r_stgcn_tconv3_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
+    'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
     'p2r_stgcn_tconv_weight_grad': lambda a: 'tconv_weight_grad' if a[3] == 3 else None,
 }
 
@@ -154,7 +155,7 @@ def issued_mfma_flops(batch, frames):
     out = {'gcn_forward': int(tables.stream_c[:, hdr].sum()) * per_rec * tiles16,
            'gcn_data_gradient': int(tables.stream_r[:, hdr].sum()) * per_rec * tiles16}
     out.update(gcn_op.grad_kernel_mfma_flops(tables, batch, frames))
-    out['tconv2_forward'] = out['tconv2_data_gradient'] = 3 * V * per_rec * tiles16
+    out['tconv_forward'] = out['tconv_data_gradient'] = 3 * V * per_rec * tiles16
     out['tconv_weight_grad'] = 3 * 2.0 * 64 * 64 * batch * frames * V
     cols = batch * frames * V
     nnz = int((A != 0).sum())
