@@ -18,13 +18,13 @@ def load(d):
         d_ = int(r['Dispatch_Id'])
         if d_ not in dur: continue
         n = dur[d_][1]
-        for key in ('gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel'):
+        for key in ('gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn3_dw_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel'):
             if key in n:
                 acc[key][r['Counter_Name']].append(float(r['Counter_Value'])); acc[key]['_ns_' + r['Counter_Name']].append(dur[d_][0])
     return acc
 a, b = load('/tmp/pm1'), load('/tmp/pm2')
 out = {'source': 'tools/pmc_mfma.sh over tools/dev_gcn_time.py (N=32, T=1024, V=53), MI355X; counters averaged per launch', 'kernels': {}}
-for k in ('gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel'):
+for k in ('gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn3_dw_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel'):
     if not a[k].get('SQ_WAVE_CYCLES') or not b[k].get('GRBM_GUI_ACTIVE'): continue
     mean = lambda v: sum(v) / len(v)
     ghz = mean(b[k]['GRBM_GUI_ACTIVE']) / 8.0 / mean(b[k]['_ns_GRBM_GUI_ACTIVE'])        # 8 XCDs report separately
