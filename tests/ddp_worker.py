@@ -62,6 +62,14 @@ def main():
     dist.all_reduce(bad)
     assert int(bad.item()) == 0, f'{int(bad.item())} parameter tensors differ across ranks'
     log = trainer.net._get_ddp_logging_data()
+    # the per-step exchange is what DESIGN.md section 7 states: 8,174,532 + 1,600 gradient bytes, 147,380 buffer bytes
+    assert log['total_parameter_size_bytes'] == 8176132 and log['broadcast_buffers'] == 1, log
+    assert sum(b.numel() * b.element_size() for b in trainer.net.module.buffers()) == 147380
+    if not share:
+        # one rank per GPU: every rank stages its batches through its OWN pinned pool and copies to its own device
+        probe = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()
+        assert probe.is_pinned() and torch.cuda.current_device() == local_rank
+        assert all(p.device.index == local_rank for p in trainer.net.module.parameters())
     if rank == 0:
         print(json.dumps({'world': world, 'backend': dist.get_backend(), 'steps': i + 1,
                           'loss_total': losses['total'],

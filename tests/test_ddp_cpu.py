@@ -26,6 +26,12 @@ def _worker(rank, world, port, out):
     torch.manual_seed(42)
     net = DDP(METHODS.get('P2RNet')(cfg))
     trainer = Trainer(cfg, net, load_optimizer(cfg.config, net), torch.device('cpu'))
+    # what crosses the wire per step, as DDP itself reports it: one f32 bucket + the f64 heading means, and the
+    # module buffers (BatchNorm statistics, adjacency) broadcast from rank 0 before every forward
+    log = net._get_ddp_logging_data()
+    assert log['broadcast_buffers'] == 1 and log['num_parameter_tensors'] == 131
+    assert log['total_parameter_size_bytes'] == 8176132
+    assert sum(b.numel() * b.element_size() for b in net.module.buffers()) == 147380
     torch.manual_seed(7)                 # same mixture noise on both ranks: only the data differs
     with cpu_ops():
         losses = trainer.train_step(make_batch(2, 32, seed=50, rank=rank))
