@@ -227,7 +227,10 @@ int p2r_stgcn_gcn2_forward(int N, int T, int V, int K, int ltot, const float *x,
  * form 0 (column lists, forward) / 1 (row lists, data gradient) -- pose2room_amd.p2rnet.gcn_tables.pattern_signature
  * of the caller's tables must equal it, every other adjacency goes through p2r_stgcn_gcn2_forward.
  * Arguments as p2r_stgcn_gcn2_forward without the stream; additionally T % 16 == 0 and x, z, addend 16-byte aligned
- * (P2R_EINVAL otherwise: use the second generation). */
+ * (P2R_EINVAL otherwise: use the second generation).
+ * stats_partial of a forward-statistics launch (no bwd_*) is [*n_partials][64][3] = (count, mean, M2) per workgroup
+ * and channel -- sums about a pivot per (wave, row), merged with their counts at the end of the kernel, so the
+ * variance survives |mean| >> std (p2r_bn_finalize width 3); with bwd_* it is [*n_partials][64][2] as before. */
 unsigned long long p2r_stgcn_gcn3_signature(int form);
 int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const float *x, const float *Wp,
                            const float *coef, const float *bias_cv, const float *addend, float *z,
@@ -290,8 +293,10 @@ int p2r_stgcn_gcn_coef_grad(int N, int T, int V, int K, const int *Lk_host,
 
 /* ---- BatchNorm + residual + ReLU of st_gcn_block (stgcn_layers.py:399-439) -------- */
 
-/* per-row partial sums for the batch statistics: x viewed as [rows = N*C][L] ->
- * partial [rows][2] = (sum x, sum x^2); the caller combines rows of a channel. */
+/* per-row partial statistics for the batch statistics: x viewed as [rows = N*C][L] ->
+ * partial [rows][3] = (L, mean of the row, M2 = sum (x - mean)^2), taken about a pivot (the row's first
+ * element) so that the variance survives |mean| >> std in fp32; p2r_bn_finalize (width 3) merges the rows
+ * of a channel. */
 int p2r_bn_stats(int rows, int L, const float *x, float *partial, void *stream);
 
 /* y = relu?(x * scale[c] + shift[c] + res?)  over x (N,C,L); res may be NULL.
@@ -318,14 +323,16 @@ int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const float *y,
                      int relu, const float *mscale, const float *mshift,
                      float *dx, float *dres, void *stream);
 
-/* statistics finalisation (one small launch instead of a dozen elementwise ones): partial [P][C][2] =
- * (sum, sum of squares) rows from p2r_bn_stats (P = N) or from the conv epilogues' stats_partial,
- * M = elements per channel.  out [4][C] = mean, invstd = 1/sqrt(var + eps), scale = gamma*invstd,
+/* statistics finalisation (one small launch instead of a dozen elementwise ones): partial [P][C][width];
+ * width 3 = (count, mean, M2) entries from p2r_bn_stats (P = N) or from the gcn3 / tconv3 epilogues'
+ * stats_partial, merged in fp64 as mean = sum n_p mean_p / n, M2 = sum [M2_p + n_p (mean_p - mean)^2];
+ * width 2 = (sum, sum of squares) entries from the first- and second-generation conv epilogues;
+ * M = elements per channel (width 3: the counts of the entries are used).  out [4][C] = mean, invstd = 1/sqrt(var + eps), scale = gamma*invstd,
  * shift = beta - mean*scale (biased variance, fp64 combination).  momentum >= 0 also updates
  * running_mean / running_var in place as nn.BatchNorm does (unbiased variance); momentum < 0 leaves
  * them untouched (they may be NULL then).  num_batches_tracked (device int64 scalar, may be NULL) is
  * incremented by one, as nn.BatchNorm's forward does in training mode. */
-int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma,
+int p2r_bn_finalize(int P, int C, int width, const float *partial, double M, const float *gamma,
                     const float *beta, double eps, double momentum, float *running_mean,
                     float *running_var, long long *num_batches_tracked, float *out, void *stream);
 
@@ -371,8 +378,9 @@ int p2r_stgcn_tconv2_forward(int N, int T, int V, int taps, const float *x, cons
                              int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
 
 /* Third generation of the same operator (csrc/stgcn_tconv3.hip): per-wave straight-line programs, in-place MFMA
- * blocks, precomputed DMA piece offsets (the recipe of p2r_stgcn_gcn3_forward).  Same arguments and results; requires
- * T % 16 == 0 and x, out, bwd_z 16-byte aligned (P2R_EINVAL otherwise: use p2r_stgcn_tconv2_forward). */
+ * blocks, precomputed DMA piece offsets (the recipe of p2r_stgcn_gcn3_forward).  Same arguments and results, except
+ * that the forward statistics are [*n_partials][64][3] = (count, mean, M2) entries as p2r_stgcn_gcn3_forward writes
+ * them; requires T % 16 == 0 and x, out, bwd_z 16-byte aligned (P2R_EINVAL otherwise: use p2r_stgcn_tconv2_forward). */
 int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
                              const float *Wp, const float *bias, float *out, float *stats_partial,
                              int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);

@@ -47,24 +47,33 @@ __device__ __forceinline__ void block_sum2(float &a, float &b) {
   for (int i = 0; i < BN_THREADS / 64; ++i) { a += sa[i]; b += sb[i]; }
 }
 
-// partial[row] = (sum x, sum x^2) over the row of length L.
+// partial[row] = (L, mean, M2 = sum (x - mean)^2) of the row of length L.  Sums are taken about a pivot (the row's
+// first element): sum x^2 - (sum x)^2 / L in fp32 loses the variance once |mean| >> std (relative error of the
+// variance ~ 1e-7 mean^2 / var), differences from a value of the row itself do not.
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int L, const float *__restrict__ x,
-                                                              float2 *__restrict__ partial) {
+                                                              float *__restrict__ partial) {
   const float *row = x + (size_t)blockIdx.x * L;
+  const float c = row[0];
   float s = 0.f, q = 0.f;
   const bool vec = ((uintptr_t)row % 16 == 0);
   const int L4 = vec ? (L >> 2) : 0;
   for (int i = threadIdx.x; i < L4; i += BN_THREADS) {
-    const float4 v = ld_stream(row + 4 * i);
+    float4 v = ld_stream(row + 4 * i);
+    v.x -= c; v.y -= c; v.z -= c; v.w -= c;
     s += (v.x + v.y) + (v.z + v.w);
     q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   for (int i = (L4 << 2) + threadIdx.x; i < L; i += BN_THREADS) {
-    const float v = row[i];
+    const float v = row[i] - c;
     s += v; q += v * v;
   }
   block_sum2(s, q);
-  if (threadIdx.x == 0) partial[blockIdx.x] = make_float2(s, q);
+  if (threadIdx.x == 0) {
+    const float n = (float)L, d = s / n;
+    partial[3 * (size_t)blockIdx.x] = n;
+    partial[3 * (size_t)blockIdx.x + 1] = c + d;
+    partial[3 * (size_t)blockIdx.x + 2] = fmaxf(q - s * d, 0.f);
+  }
 }
 
 // y = relu?(x * scale[c] + shift[c] + res)
@@ -236,11 +245,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
 
 }  // namespace
 
-extern "C" int p2r_bn_stats(int rows, int L, const float *x, float *partial /* [rows][2] */, void *stream) {
+extern "C" int p2r_bn_stats(int rows, int L, const float *x, float *partial /* [rows][3] */, void *stream) {
   if (rows < 0 || L <= 0) return P2R_EINVAL;
   if (rows == 0) return P2R_OK;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(BN_THREADS), 0, p2r_stream(stream), L, x,
-                     reinterpret_cast<float2 *>(partial));
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(rows), dim3(BN_THREADS), 0, p2r_stream(stream), L, x, partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -305,8 +313,11 @@ extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const floa
 }
 
 // ---- statistics finalisation: kernel partials -> per-channel constants, one tiny launch -------------
-// partial [P][C][2] (bn_stats rows (n, c), or the conv epilogues' per-workgroup rows); one workgroup per
-// channel sums its P pairs in fp64.
+// partial [P][C][width]; one workgroup per channel combines its P entries in fp64.
+//   width 3: (count, mean, M2) per entry -- p2r_bn_stats rows (n, c) and the third-generation conv epilogues; merged
+//            as mean = sum n_p mean_p / n, M2 = sum [M2_p + n_p (mean_p - mean)^2] (every term non-negative: no
+//            cancellation whatever the mean is);
+//   width 2: (sum, sum of squares) per entry -- the first- and second-generation conv epilogues (fallback shapes).
 namespace {
 
 constexpr int FIN_THREADS = 256;
@@ -325,7 +336,7 @@ __device__ __forceinline__ void fin_block_sum(double &a, double &b) {
 
 // out [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running statistics updated in
 // place with `momentum` (unbiased variance, like nn.BatchNorm) unless momentum < 0.
-__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(int P, int C, const float2 *__restrict__ partial,
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(int P, int C, int width, const float *__restrict__ partial,
                                                                   double M, const float *__restrict__ gamma,
                                                                   const float *__restrict__ beta, double eps,
                                                                   double momentum, float *__restrict__ running_mean,
@@ -334,15 +345,38 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(int P, int C, 
                                                                   float *__restrict__ out) {
   const int c = blockIdx.x;
   if (c == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  double s = 0.0, q = 0.0;
-  for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
-    const float2 v = partial[(size_t)p * C + c];
-    s += (double)v.x; q += (double)v.y;
+  double s = 0.0, q = 0.0;                 // sum and M2 of the channel
+  if (width == 3) {
+    double n = 0.0;
+    for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
+      const float *e = partial + ((size_t)p * C + c) * 3;
+      n += (double)e[0]; s += (double)e[0] * (double)e[1];
+    }
+    fin_block_sum(n, s);
+    const double mean = s / n;
+    __syncthreads();                       // fin_block_sum's staging is reused below
+    double m2 = 0.0, unused = 0.0;
+    for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
+      const float *e = partial + ((size_t)p * C + c) * 3;
+      const double d = (double)e[1] - mean;
+      m2 += (double)e[2] + (double)e[0] * d * d;
+    }
+    fin_block_sum(m2, unused);
+    M = n;                                 // the entries carry their own counts
+    s = mean * n;
+    q = m2;
+  } else {
+    for (int p = threadIdx.x; p < P; p += FIN_THREADS) {
+      const float *e = partial + ((size_t)p * C + c) * 2;
+      s += (double)e[0]; q += (double)e[1];
+    }
+    fin_block_sum(s, q);
+    const double mean = s / M;
+    q = q - mean * mean * M;               // M2
   }
-  fin_block_sum(s, q);
   if (threadIdx.x == 0) {
     const double mean = s / M;
-    double var = q / M - mean * mean;
+    double var = q / M;
     if (var < 0.0) var = 0.0;
     const float mean_f = (float)mean, invstd_f = (float)(1.0 / sqrt(var + eps));
     const float scale = gamma[c] * invstd_f;
@@ -379,13 +413,12 @@ __global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(int P, int
 
 }  // namespace
 
-extern "C" int p2r_bn_finalize(int P, int C, const float *partial, double M, const float *gamma, const float *beta,
-                               double eps, double momentum, float *running_mean, float *running_var,
+extern "C" int p2r_bn_finalize(int P, int C, int width, const float *partial, double M, const float *gamma,
+                               const float *beta, double eps, double momentum, float *running_mean, float *running_var,
                                long long *num_batches_tracked, float *out, void *stream) {
-  if (P <= 0 || C <= 0 || M <= 0.0) return P2R_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, p2r_stream(stream), P, C,
-                     reinterpret_cast<const float2 *>(partial), M, gamma, beta, eps, momentum, running_mean,
-                     running_var, num_batches_tracked, out);
+  if (P <= 0 || C <= 0 || M <= 0.0 || (width != 2 && width != 3)) return P2R_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_THREADS), 0, p2r_stream(stream), P, C, width, partial, M, gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches_tracked, out);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

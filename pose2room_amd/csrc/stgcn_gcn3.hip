@@ -49,6 +49,17 @@ struct G3Params {
 
 constexpr int g3_slot_joints[2][G3_NW][G3_SLOTS] = {G3_SLOT_JOINTS_0, G3_SLOT_JOINTS_1};
 constexpr int g3_plane0[2][G3_NW] = {G3_PLANE0_0, G3_PLANE0_1};            // first plane of each wave's schedule
+constexpr int g3_first_slot(int form, int w) {                             // first used accumulator slot of a wave
+  for (int i = 0; i < G3_SLOTS; ++i)
+    if (g3_slot_joints[form][w][i] >= 0) return i;
+  return 0;
+}
+constexpr int g3_wave_joints(int form, int w) {                            // joints a wave owns
+  int n = 0;
+  for (int i = 0; i < G3_SLOTS; ++i) n += g3_slot_joints[form][w][i] >= 0;
+  return n;
+}
+constexpr int G3_ST = 3;   // floats per (wave, row) statistics entry: (sum, sum of squares) about the pivot, pivot
 
 __device__ __forceinline__ unsigned g3_lds_addr(const float *p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
@@ -168,8 +179,8 @@ __device__ __forceinline__ void g3_wave_main(
     const unsigned char *__restrict__ bwd_mask) {
   constexpr int V = G3_V, RS = G3_RS, BUF = G3_BUF, NW = G3_NW, SLOTS = G3_SLOTS;
   constexpr int wave = WAVE;
-  float *rowstat = lds + 2 * BUF;                                         // [NW][64][2]
-  float *bias_l = rowstat + NW * 128;                                     // [64][V] bias table (zeros without bias)
+  float *rowstat = lds + 2 * BUF;                                         // [NW][64][G3_ST]
+  float *bias_l = rowstat + NW * 64 * G3_ST;                              // [64][V] bias table (zeros without bias)
   float *bstat = bias_l + 64 * V;                                         // [64][2] (mean, invstd) of the BWD epilogue
   float *coef_l = bstat + 128;                                            // [ltot][V] coefficient table
 
@@ -271,25 +282,33 @@ __device__ __forceinline__ void g3_wave_main(
     }
 
     // ---- epilogue: D[row = 16 m + 4 g + q][frame r] of joint sj[i]; statistics of the stored values.
-    float *rs = rowstat + wave * 128;
+    // The sums are taken about a pivot per (wave, row) -- the mean of the first 16 values the wave produces for the
+    // row -- and merged at the end of the kernel with the counts (see bn_act.hip: sum v^2 - (sum v)^2 / n in fp32
+    // loses the variance once |mean| >> std).
+    float *rs = rowstat + wave * 64 * G3_ST;
     if (!BWD && want_stats) {
+      constexpr int I0 = g3_first_slot(FORM, WAVE);
+      const bool first = tile == (int)blockIdx.x;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          float *e = rs + G3_ST * (16 * m + 4 * g + q);
+          const float c = first ? p2r_row16_sum(acc[I0][m][q]) * 0.0625f : e[2];
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int i = 0; i < SLOTS; ++i)
             if (sj[i] >= 0) {
-              const float v = acc[i][m][q];
+              const float v = acc[i][m][q] - c;
               s1 += v;
               s2 = fmaf(v, v, s2);
             }
           s1 = p2r_row16_sum(s1);
           s2 = p2r_row16_sum(s2);
-          if (r == 0) {             // slot owned by (wave, row): plain read-modify-write, deterministic
-            rs[2 * (16 * m + 4 * g + q)] += s1;
-            rs[2 * (16 * m + 4 * g + q) + 1] += s2;
+          if (r == 0) {             // entry owned by (wave, row): plain read-modify-write, deterministic
+            e[0] += s1;
+            e[1] += s2;
+            if (first) e[2] = c;
           }
         }
     }
@@ -362,8 +381,8 @@ __device__ __forceinline__ void g3_wave_main(
               s2 += __shfl_xor(s2, off, 64);
             }
             if (lane == 0) {
-              rs[2 * c] += s1;
-              rs[2 * c + 1] += s2;
+              rs[G3_ST * c] += s1;
+              rs[G3_ST * c + 1] += s2;
             }
           }
         } else {
@@ -398,11 +417,11 @@ __global__ __launch_bounds__(G3_NW * 64, 2) void gcn3_kernel(
   constexpr int V = G3_V, BUF = G3_BUF, NW = G3_NW;
   extern __shared__ float lds[];
   float *rowstat = lds + 2 * BUF;
-  float *bias_l = rowstat + NW * 128;
+  float *bias_l = rowstat + NW * 64 * G3_ST;
   float *bstat = bias_l + 64 * V;
   float *coef_l = bstat + 128;
   const int tid = threadIdx.x;
-  for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
+  for (int e = tid; e < NW * 64 * G3_ST; e += NW * 64) rowstat[e] = 0.f;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
   for (int e = tid; e < ltot * V; e += NW * 64) coef_l[e] = coef[e];
   if (tid < 64) {
@@ -425,11 +444,34 @@ __global__ __launch_bounds__(G3_NW * 64, 2) void gcn3_kernel(
 
   if (stats_partial) {
     __syncthreads();
-    if (tid < 128) {
-      float t = 0.f;
+    if constexpr (BWD) {          // [64][2] plain sums
+      if (tid < 128) {
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += rowstat[w * 128 + tid];
-      stats_partial[(size_t)blockIdx.x * 128 + tid] = t;
+        for (int w = 0; w < NW; ++w) t += rowstat[(w * 64 + (tid >> 1)) * G3_ST + (tid & 1)];
+        stats_partial[(size_t)blockIdx.x * 128 + tid] = t;
+      }
+    } else if (tid < 64) {        // [64][3] = (count, mean, M2) of the workgroup's tiles: the eight waves' entries merged
+      const int ntiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+      const float per_joint = (float)(ntiles * G3_F);
+      float nw[NW], mw[NW], qw[NW];
+      float msum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float *e = rowstat + (w * 64 + tid) * G3_ST;
+        nw[w] = per_joint * (float)g3_wave_joints(FORM, w);
+        const float d = e[0] / nw[w];
+        mw[w] = e[2] + d;
+        qw[w] = fmaxf(e[1] - e[0] * d, 0.f);
+        msum = fmaf(nw[w], mw[w] - mw[0], msum);          // about the first wave's mean: small terms
+      }
+      const float n = per_joint * (float)V;
+      const float mean = mw[0] + msum / n;
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m2 += qw[w] + nw[w] * (mw[w] - mean) * (mw[w] - mean);
+      float *o = stats_partial + (size_t)blockIdx.x * 192 + 3 * tid;
+      o[0] = n; o[1] = mean; o[2] = m2;
     }
   }
 }
@@ -482,7 +524,7 @@ extern "C" int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int 
   const int blocks = (int)(tiles < 256 ? tiles : 256);
   if (n_partials) *n_partials = blocks;
   if (!z) return P2R_OK;
-  const size_t lds = (size_t)2 * G3_BUF * sizeof(float) + (size_t)G3_NW * 128 * sizeof(float) +
+  const size_t lds = (size_t)2 * G3_BUF * sizeof(float) + (size_t)G3_NW * 64 * G3_ST * sizeof(float) +
                      (size_t)64 * V * sizeof(float) + 128 * sizeof(float) + (size_t)ltot * V * sizeof(float);
   if (lds > 160 * 1024) return P2R_EINVAL;
   if (form == 0) {

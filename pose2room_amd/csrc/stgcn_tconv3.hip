@@ -21,6 +21,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T3_F = 16, T3_CP = 16, T3_NPH = 4, T3_NW = 8, T3_SLOTS = 7, T3_V = 53;
+constexpr int T3_ST = 3;   // floats per (wave, row) statistics entry: (sum, sum of squares) about the pivot, pivot
 constexpr int T3_RS = T3_F * T3_V;                  // 848
 constexpr int T3_MAIN = T3_CP * T3_RS;              // floats of the 16-frame part of a slice
 constexpr int T3_HRS = 2 * T3_V;                    // halo row: frame t0-1, frame t0+16
@@ -82,8 +83,8 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   constexpr int j0 = WAVE < 5 ? 7 * WAVE : 35 + 6 * (WAVE - 5);
   constexpr int nslots = WAVE < 5 ? 7 : 6;
   constexpr int PW16 = T3_PW16, PWH = TAPS > 1 ? T3_PWH : 0;
-  float *rowstat = lds + 2 * BUF;                     // [NW][64][2]
-  float *aff = rowstat + NW * 128;                    // [64][2] (scale, shift) of the input transform
+  float *rowstat = lds + 2 * BUF;                     // [NW][64][T3_ST]
+  float *aff = rowstat + NW * 64 * T3_ST;                  // [64][2] (scale, shift) of the input transform
   float *bias_l = aff + 128;                          // [64]
   float *bstat = bias_l + 64;                         // [64][2] (mean, invstd) of the BWD epilogue
 
@@ -244,24 +245,29 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
     }
 
     // ---- epilogue: statistics of the tile, then the tile itself through LDS as whole rows ------------------------
-    float *rs = rowstat + wave * 128;
+    // sums about a pivot per (wave, row), merged with the counts at the end of the kernel (see stgcn_gcn3.hip)
+    float *rs = rowstat + wave * 64 * T3_ST;
     if (!BWD && want_stats) {
+      const bool first = tile == (int)blockIdx.x;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          float *e = rs + T3_ST * (16 * m + 4 * g + q);
+          const float c = first ? p2r_row16_sum(acc[0][m][q]) * 0.0625f : e[2];
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int i = 0; i < nslots; ++i) {
-            const float v = acc[i][m][q];
+            const float v = acc[i][m][q] - c;
             s1 += v;
             s2 = fmaf(v, v, s2);
           }
           s1 = p2r_row16_sum(s1);
           s2 = p2r_row16_sum(s2);
           if (r == 0) {
-            rs[2 * (16 * m + 4 * g + q)] += s1;
-            rs[2 * (16 * m + 4 * g + q) + 1] += s2;
+            e[0] += s1;
+            e[1] += s2;
+            if (first) e[2] = c;
           }
         }
     }
@@ -320,8 +326,8 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
               s2 += __shfl_xor(s2, off, 64);
             }
             if (lane == 0) {
-              rs[2 * c] += s1;
-              rs[2 * c + 1] += s2;
+              rs[T3_ST * c] += s1;
+              rs[T3_ST * c + 1] += s2;
             }
           }
         } else {
@@ -349,11 +355,11 @@ __global__ __launch_bounds__(T3_NW * 64, 2) void tconv3_kernel(
   constexpr int NW = T3_NW;
   extern __shared__ float lds[];
   float *rowstat = lds + 2 * T3_BUF;
-  float *aff = rowstat + NW * 128;
+  float *aff = rowstat + NW * 64 * T3_ST;
   float *bias_l = aff + 128;
   float *bstat = bias_l + 64;
   const int tid = threadIdx.x;
-  for (int e = tid; e < NW * 128; e += NW * 64) rowstat[e] = 0.f;
+  for (int e = tid; e < NW * 64 * T3_ST; e += NW * 64) rowstat[e] = 0.f;
   if (tid < 64) {
     aff[2 * tid] = XFORM ? scale[tid] : (BWD ? bwd_fin[128 + tid] : 1.f);
     aff[2 * tid + 1] = XFORM ? shift[tid] : (BWD ? bwd_fin[192 + tid] : 0.f);
@@ -375,11 +381,34 @@ __global__ __launch_bounds__(T3_NW * 64, 2) void tconv3_kernel(
   }
   if (stats_partial) {
     __syncthreads();
-    if (tid < 128) {
-      float t = 0.f;
+    if constexpr (BWD) {          // [64][2] plain sums
+      if (tid < 128) {
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += rowstat[w * 128 + tid];
-      stats_partial[(size_t)blockIdx.x * 128 + tid] = t;
+        for (int w = 0; w < NW; ++w) t += rowstat[(w * 64 + (tid >> 1)) * T3_ST + (tid & 1)];
+        stats_partial[(size_t)blockIdx.x * 128 + tid] = t;
+      }
+    } else if (tid < 64) {        // [64][3] = (count, mean, M2) of the workgroup's tiles: the eight waves' entries merged
+      const int ntiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+      const float per_joint = (float)(ntiles * T3_F);
+      float nw[NW], mw[NW], qw[NW];
+      float msum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float *e = rowstat + (w * 64 + tid) * T3_ST;
+        nw[w] = per_joint * (float)(w < 5 ? 7 : 6);       // joints per wave: see t3_wave_main
+        const float d = e[0] / nw[w];
+        mw[w] = e[2] + d;
+        qw[w] = fmaxf(e[1] - e[0] * d, 0.f);
+        msum = fmaf(nw[w], mw[w] - mw[0], msum);          // about the first wave's mean: small terms
+      }
+      const float n = per_joint * (float)T3_V;
+      const float mean = mw[0] + msum / n;
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m2 += qw[w] + nw[w] * (mw[w] - mean) * (mw[w] - mean);
+      float *o = stats_partial + (size_t)blockIdx.x * 192 + 3 * tid;
+      o[0] = n; o[1] = mean; o[2] = m2;
     }
   }
 }
@@ -420,7 +449,7 @@ extern "C" int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const flo
   const int blocks = (int)(tiles < 256 ? tiles : 256);
   if (n_partials) *n_partials = blocks;
   if (!out) return P2R_OK;
-  const size_t lds = (size_t)2 * T3_BUF * sizeof(float) + (size_t)T3_NW * 128 * sizeof(float) +
+  const size_t lds = (size_t)2 * T3_BUF * sizeof(float) + (size_t)T3_NW * 64 * T3_ST * sizeof(float) +
                      (size_t)(128 + 64 + 128) * sizeof(float);
 #define P2R_T3(XF, BW) (taps == 3 ? tconv3_launch<XF, BW, 3>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream) \
                                    : tconv3_launch<XF, BW, 1>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream))

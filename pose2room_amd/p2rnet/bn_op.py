@@ -21,9 +21,9 @@ def _rows(x):
 
 
 def _stats_partial(x):
-    """per-(sample, channel) (sum, sum of squares) rows [N, C, 2] from one HBM pass."""
+    """per-(sample, channel) (count, mean, M2) rows [N, C, 3] from one HBM pass (see `moments`)."""
     N, C, L = _rows(x)
-    part = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((N, C, 3), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().p2r_bn_stats(N * C, L, _lib.ptr(x), _lib.ptr(part), _lib.current_stream(x.device)),
                    "bn_stats")
@@ -37,17 +37,18 @@ def _stats(x):
 
 
 def finalize(part, M, bn):
-    """Kernel partials [P, C, 2] -> fin [4, C] = (mean, invstd, scale, shift) of BatchNorm module `bn` in one
-    launch, which also applies the running-statistics update (momentum, unbiased variance) in place."""
+    """Kernel partials [P, C, 3] or [P, C, 2] (see `moments`) -> fin [4, C] = (mean, invstd, scale, shift) of
+    BatchNorm module `bn` in one launch, which also applies the running-statistics update (momentum, unbiased
+    variance) in place."""
     part = part.contiguous()
-    P, C = part.shape[0], part.shape[1]
+    P, C, width = part.shape
     fin = torch.empty((4, C), dtype=torch.float32, device=part.device)
     if bn.momentum is None:      # cumulative moving average: the factor depends on the step counter
         mom = 1.0 / float(bn.num_batches_tracked + 1)
     else:
         mom = float(bn.momentum)
     with torch.cuda.device(part.device):
-        _lib.check(_lib.lib().p2r_bn_finalize(P, C, _lib.ptr(part), ctypes.c_double(float(M)), _lib.ptr(bn.weight),
+        _lib.check(_lib.lib().p2r_bn_finalize(P, C, width, _lib.ptr(part), ctypes.c_double(float(M)), _lib.ptr(bn.weight),
                                               _lib.ptr(bn.bias), ctypes.c_double(float(bn.eps)), ctypes.c_double(mom),
                                               _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
                                               _lib.ptr(bn.num_batches_tracked), _lib.ptr(fin),
@@ -67,9 +68,20 @@ def bwd_finalize(part, M):
 
 
 def moments(part, M):
-    """(mean, biased var) in fp64 from kernel partials [P, C, 2] = (sum, sum of squares) over M elements
-    per channel (the graph-conv / temporal-conv kernels emit these from their epilogues)."""
-    tot = part.double().sum(0)
+    """(mean, biased var) in fp64 from kernel partials over M elements per channel.
+
+    [P, C, 3] = (count, mean, M2 = sum of squared differences from that mean) per entry: the statistics pass and the
+    third-generation conv epilogues, which take their sums about a pivot so that the variance survives
+    |mean| >> std in fp32; merged as p2r_bn_finalize does.  [P, C, 2] = (sum, sum of squares): the first- and
+    second-generation conv epilogues (fallback shapes)."""
+    part = part.double()
+    if part.shape[-1] == 3:
+        n = part[..., 0]
+        tot = n.sum(0)
+        mean = (n * part[..., 1]).sum(0) / tot
+        m2 = (part[..., 2] + n * (part[..., 1] - mean) ** 2).sum(0)
+        return mean, m2 / tot, float(M)
+    tot = part.sum(0)
     mean = tot[:, 0] / M
     var = (tot[:, 1] / M - mean * mean).clamp_(min=0.0)
     return mean, var, float(M)
@@ -199,7 +211,7 @@ def supported(x, bn):
 
 
 def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None):
-    """stats: optional kernel partials [P, C, 2] of x (see `moments`) replacing the statistics pass.
+    """stats: optional kernel partials [P, C, 3 | 2] of x (see `moments`) replacing the statistics pass.
     link: a `BNLink` to hang on the result (train mode) for the graph conv that consumes it."""
     if bn.training:
         part = _stats_partial(x.contiguous()) if stats is None else stats

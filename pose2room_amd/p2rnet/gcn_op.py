@@ -116,9 +116,12 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
     ltot = coef.shape[0]
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
-        if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
-            part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
-        if form is not None and _gen3_able(x, z, addend, tables):
+        gen3 = form is not None and _gen3_able(x, z, addend, tables)
+        if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256); forward launches of
+            #                 the third generation write (count, mean, M2) entries, everything else pairs of sums
+            part = torch.empty((min(N * ((T + 15) // 16), 256), C, 3 if gen3 and bwd is None else 2),
+                               dtype=torch.float32, device=x.device)
+        if gen3:
             bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
             _lib.check(lib.p2r_stgcn_gcn3_forward(N, T, V, tables.K, ltot, int(form), _lib.ptr(x), _lib.ptr(Wp),
                                                   _lib.ptr(coef), _lib.ptr(bias_cv), _lib.ptr(addend), _lib.ptr(z),

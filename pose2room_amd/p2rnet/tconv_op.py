@@ -47,11 +47,13 @@ def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
         bz, bfin = (bwd[0], bwd[1].contiguous()) if bwd is not None else (None, None)
         with torch.cuda.device(x.device):
             st = _lib.current_stream(x.device)
-            if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256)
-                part = torch.empty((min(N * ((T + 15) // 16), 256), C, 2), dtype=torch.float32, device=x.device)
             # full tiles of aligned rows: the statically scheduled third generation; anything else the second
             gen3 = (USE_GEN3 and T % 16 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
                     and (bz is None or bz.data_ptr() % 16 == 0))
+            if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256); forward launches
+                #                 of the third generation write (count, mean, M2) entries, everything else pairs of sums
+                part = torch.empty((min(N * ((T + 15) // 16), 256), C, 3 if gen3 and bwd is None else 2),
+                                   dtype=torch.float32, device=x.device)
             fn = lib.p2r_stgcn_tconv3_forward if gen3 else lib.p2r_stgcn_tconv2_forward
             _lib.check(fn(N, T, V, Wp.shape[0], _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
                           _lib.ptr(bias), _lib.ptr(out), _lib.ptr(part), None, _lib.ptr(bz), _lib.ptr(bfin), st),
