@@ -16,6 +16,20 @@
 // Full tiles of 16-byte aligned rows only (T % 16 == 0): anything else runs on stgcn_tconv2.hip.
 #include "p2r_common.h"
 
+// Cycle trace (profiling hook, off in the product build): with -DP2R_CYCLE_TRACE the waves of workgroup 7 stamp
+// s_memtime at the section boundaries of their fourth tile; tools/dev_t3_trace.py reads the stamps back through
+// p2r_debug_t3_trace (make -C pose2room_amd/csrc clean all FLAGS="... -DP2R_CYCLE_TRACE").  DESIGN.md quotes it.
+#ifdef P2R_CYCLE_TRACE
+__device__ unsigned long long t3_trace[8 * 32];
+extern "C" int p2r_debug_t3_trace(unsigned long long *dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(t3_trace), sizeof(t3_trace));
+}
+#define T3_TRACE_TILE(tile) const bool trace_on = blockIdx.x == 7 && (tile) == 7 + 3 * (int)gridDim.x
+#define T3_MARK(i) do { if (trace_on && lane == 0) t3_trace[wave * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define T3_TRACE_TILE(tile)
+#define T3_MARK(i)
+#endif
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,22 +66,61 @@ __device__ __forceinline__ void t3_dma4(const float *base, unsigned voff, float 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
-// the 16 MFMAs of one (tap, joint) unit, accumulating in place (see stgcn_gcn3.hip)
-__device__ __forceinline__ void t3_mfma16(f32x4 (&acc)[4], const float (&a)[4][4], const float (&b)[4]) {
-  asm volatile(
+// A operands (the weights of one (tap, phase): 4 x 16 bytes per lane) live in registers the compiler does not
+// allocate -- the kernels are limited to v0..v223 (amdgpu_num_vgpr), set 0 = v[224:239], set 1 = v[240:255], named in
+// the assembly text -- and are waited for
+// explicitly.  Two reasons.  Left to the compiler, its s_waitcnt in front of their first use counts only the loads it
+// knows about -- vmcnt(0..4) -- while the hardware counter also holds the slice pieces issued after them by t3_dma16 /
+// t3_dma4; vector-memory operations retire in order, so every wave stood at the top of a visit until most of the NEXT
+// slice had arrived (all 256 workgroups at once: ~3 us of a 13 us phase).  With the count spelled out (the pieces
+// issued after the operands may stay in flight) the copy runs under the MFMAs.  And a load whose destination is a
+// compiler-visible register cannot be waited for by hand: the compiler considers the value present after the load
+// statement and is free to copy it before the wait (it did: the set rotation was hoisted above the s_waitcnt).
+#define T3_SET0 "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239"
+#define T3_SET1 "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+template <int SET>
+__device__ __forceinline__ void t3_load_a(const float *base, unsigned lane_off) {
+  if constexpr (SET == 0)
+    asm volatile("global_load_dwordx4 v[224:227], %0, %1\n\tglobal_load_dwordx4 v[228:231], %0, %1 offset:1024\n\tglobal_load_dwordx4 v[232:235], %0, %1 offset:2048\n\tglobal_load_dwordx4 v[236:239], %0, %1 offset:3072"
+                 :: "v"(lane_off), "s"(base) : "memory", T3_SET0);
+  else
+    asm volatile("global_load_dwordx4 v[240:243], %0, %1\n\tglobal_load_dwordx4 v[244:247], %0, %1 offset:1024\n\tglobal_load_dwordx4 v[248:251], %0, %1 offset:2048\n\tglobal_load_dwordx4 v[252:255], %0, %1 offset:3072"
+                 :: "v"(lane_off), "s"(base) : "memory", T3_SET1);
+}
+template <int LATER>   // LATER: vector-memory operations issued after the awaited ones that may still be in flight
+__device__ __forceinline__ void t3_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LATER) : "memory");
+}
+__device__ __forceinline__ void t3_rotate_a() {   // set 0 <- set 1
+  asm volatile("v_mov_b32 v224, v240\n\tv_mov_b32 v225, v241\n\tv_mov_b32 v226, v242\n\tv_mov_b32 v227, v243\n\tv_mov_b32 v228, v244\n\tv_mov_b32 v229, v245\n\tv_mov_b32 v230, v246\n\tv_mov_b32 v231, v247\n\tv_mov_b32 v232, v248\n\tv_mov_b32 v233, v249\n\tv_mov_b32 v234, v250\n\tv_mov_b32 v235, v251\n\tv_mov_b32 v236, v252\n\tv_mov_b32 v237, v253\n\tv_mov_b32 v238, v254\n\tv_mov_b32 v239, v255" ::: T3_SET0);
+}
+// the 16 MFMAs of one (tap, joint) unit, accumulating in place (see stgcn_gcn3.hip); A[m][s] = v[224 + 16 SET + 4 m + s]
+template <int SET>
+__device__ __forceinline__ void t3_mfma16(f32x4 (&acc)[4], const float (&b)[4]) {
+  if constexpr (SET == 0)
+    asm volatile(
       "s_nop 1\n\t"
-      "v_mfma_f32_16x16x4_f32 %0, %4, %20, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %20, %1\n\t"
-      "v_mfma_f32_16x16x4_f32 %2, %12, %20, %2\n\tv_mfma_f32_16x16x4_f32 %3, %16, %20, %3\n\t"
-      "v_mfma_f32_16x16x4_f32 %0, %5, %21, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %21, %1\n\t"
-      "v_mfma_f32_16x16x4_f32 %2, %13, %21, %2\n\tv_mfma_f32_16x16x4_f32 %3, %17, %21, %3\n\t"
-      "v_mfma_f32_16x16x4_f32 %0, %6, %22, %0\n\tv_mfma_f32_16x16x4_f32 %1, %10, %22, %1\n\t"
-      "v_mfma_f32_16x16x4_f32 %2, %14, %22, %2\n\tv_mfma_f32_16x16x4_f32 %3, %18, %22, %3\n\t"
-      "v_mfma_f32_16x16x4_f32 %0, %7, %23, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %23, %1\n\t"
-      "v_mfma_f32_16x16x4_f32 %2, %15, %23, %2\n\tv_mfma_f32_16x16x4_f32 %3, %19, %23, %3"
-      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
-      : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]),
-        "v"(a[2][0]), "v"(a[2][1]), "v"(a[2][2]), "v"(a[2][3]), "v"(a[3][0]), "v"(a[3][1]), "v"(a[3][2]), "v"(a[3][3]),
-        "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+      "v_mfma_f32_16x16x4_f32 %0, v224, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, v228, %4, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v232, %4, %2\n\tv_mfma_f32_16x16x4_f32 %3, v236, %4, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v225, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, v229, %5, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v233, %5, %2\n\tv_mfma_f32_16x16x4_f32 %3, v237, %5, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v226, %6, %0\n\tv_mfma_f32_16x16x4_f32 %1, v230, %6, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v234, %6, %2\n\tv_mfma_f32_16x16x4_f32 %3, v238, %6, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v227, %7, %0\n\tv_mfma_f32_16x16x4_f32 %1, v231, %7, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v235, %7, %2\n\tv_mfma_f32_16x16x4_f32 %3, v239, %7, %3"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+  else
+    asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v240, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, v244, %4, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v248, %4, %2\n\tv_mfma_f32_16x16x4_f32 %3, v252, %4, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v241, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, v245, %5, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v249, %5, %2\n\tv_mfma_f32_16x16x4_f32 %3, v253, %5, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v242, %6, %0\n\tv_mfma_f32_16x16x4_f32 %1, v246, %6, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v250, %6, %2\n\tv_mfma_f32_16x16x4_f32 %3, v254, %6, %3\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, v243, %7, %0\n\tv_mfma_f32_16x16x4_f32 %1, v247, %7, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %2, v251, %7, %2\n\tv_mfma_f32_16x16x4_f32 %3, v255, %7, %3"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
 
 // XFORM: input transform relu(x * scale + shift) applied in place to each slice; BWD (data-gradient instance): the
@@ -125,10 +178,10 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
     hmask |= (unsigned)h << i;
   }
   // base = address of (channel row 0 of the slice, frame t0 - 1); lo / hi: frame t0-1 / t0+16 exists in the sequence
+  // halo pieces first: the N16 main pieces are then the last vector-memory operations of the wave (t3_wait_a<N16>)
+  constexpr int N16 = (T3_PIECES16 - WAVE + NW - 1) / NW;   // every piece is whole: NV4 = 53 * 64
+  static_assert(T3_NV4 == T3_PIECES16 * 64, "partial main piece");
   auto copy_slice = [&](float *buf, const float *base, bool lo, bool hi) {
-#pragma unroll
-    for (int i = 0; i < PW16; ++i)
-      if (moff[i] != 0xffffffffu) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
 #pragma unroll
     for (int i = 0; i < PWH; ++i)
       if (hoff[i] != 0xffffffffu) {
@@ -136,25 +189,33 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
         if (in) t3_dma4(base, hoff[i], buf + MAIN + (i * NW + wave) * 64);
         else buf[MAIN + (i * NW + wave) * 64 + lane] = fillv;
       }
+#pragma unroll
+    for (int i = 0; i < N16; ++i) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
   };
 
   f32x4 acc[SLOTS][4];
-  float aS[2][4][4];
-  auto load_a = [&](float (&a)[4][4], int tp, int ph) {
-    const float4 *wp = reinterpret_cast<const float4 *>(Wp) + ((size_t)(tp * T3_NPH + ph) * 4) * 64 + lane;
+  // A-operand sets: visit `tp` of a phase multiplies with set tp & 1 and loads the next visit's operands into the
+  // other one; a phase ends with the next phase's first operands in set 1 (TAPS is odd), moved to set 0 once they
+  // have arrived
+  static_assert(TAPS & 1, "set rotation");
+  const unsigned a_lane = (unsigned)lane * 16u;
+  auto a_base = [&](int tp, int ph) { return Wp + (size_t)(tp * T3_NPH + ph) * 4 * 64 * 4; };
+
+  // BWD: a wave stores rows 2 wave + {0, 1} of every 16-row group, i.e. the same eight channels in every tile: the
+  // two sums of each are kept per lane across the tiles and combined over the lanes once, at the end of the kernel
+  // (per tile, the 6-step lane reduction and the LDS update cost a fifth of the tile: cycle trace, round 3)
+  float bsum[BWD ? 4 : 1][2][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float4 u = wp[m * 64];
-      a[m][0] = u.x; a[m][1] = u.y; a[m][2] = u.z; a[m][3] = u.w;
-    }
-  };
+  for (int m = 0; m < (BWD ? 4 : 1); ++m)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) bsum[m][rr][0] = bsum[m][rr][1] = 0.f;
 
   int tile = blockIdx.x;
   if (tile < p.total_tiles) {       // prologue: phase 0 of the first tile
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * T3_F;
     copy_slice(lds, x + (size_t)seq * 64 * row_stride + (size_t)t0 * V - V, t0 > 0, t0 + T3_F < p.T);
   }
-  load_a(aS[0], 0, 0);
+  t3_load_a<1>(a_base(0, 0), a_lane);
 
   for (; tile < p.total_tiles; tile += gridDim.x) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * T3_F;
@@ -165,6 +226,8 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * T3_F : 0;
     const float *nxg = x + (size_t)nseq * 64 * row_stride + (size_t)nt0 * V;
+    T3_TRACE_TILE(tile);
+    T3_MARK(0);
 
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i)
@@ -175,7 +238,10 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
 
 #pragma unroll 1
     for (int ph = 0; ph < T3_NPH; ++ph) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces of slice `ph` have landed
+      T3_MARK(1 + 4 * ph);
+      t3_wait_vm<0>();                                      // own pieces of slice `ph` and the phase's first operands have landed
+      t3_rotate_a();
+      T3_MARK(2 + 4 * ph);
       __syncthreads();                                      // ... everybody's; and nobody reads the other buffer any more
       float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
       const bool copy = ph + 1 < T3_NPH || has_next;
@@ -206,16 +272,27 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
         __syncthreads();
       }
 
+      T3_MARK(3 + 4 * ph);
       const char *bufc = reinterpret_cast<const char *>(lds + (ph & 1) * BUF);
       float b_cur[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) b_cur[s] = *reinterpret_cast<const float *>(bufc + rd[0][s]);
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp) {
+        // this visit's operands (requested one visit ago): the second visit leaves the main pieces of the next slice,
+        // issued after them, in flight; the third follows them in the queue -- by then they have been under way for
+        // two thirds of the phase
+        if (tp == 1) {
+          if (copy) t3_wait_vm<N16>();
+          else t3_wait_vm<0>();
+        } else if (tp > 1) {
+          t3_wait_vm<0>();
+        }
         {   // A operands of the next (tap, phase) into the other set; every piece of the next slice in the first visit
           int ntp = tp + 1, nph = ph;
           if (ntp == TAPS) { ntp = 0; nph = (ph + 1) & (T3_NPH - 1); }
-          load_a(aS[(tp & 1) ^ 1], ntp, nph);
+          if (tp & 1) t3_load_a<0>(a_base(ntp, nph), a_lane);
+          else t3_load_a<1>(a_base(ntp, nph), a_lane);
         }
         if (tp == 0 && copy) copy_slice(buf_nxt, src, slo, shi);
 #pragma unroll
@@ -228,22 +305,21 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
             for (int s = 0; s < 4; ++s) b_nxt[s] = *reinterpret_cast<const float *>(bufc + rd[ntp2][s] + 4 * ni);
           }
           __builtin_amdgcn_sched_barrier(0);
-          t3_mfma16(acc[i], aS[tp & 1], b_cur);
+          if (tp & 1) t3_mfma16<1>(acc[i], b_cur);
+          else t3_mfma16<0>(acc[i], b_cur);
           __builtin_amdgcn_sched_barrier(0);
           if (ntp2 < TAPS) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) b_cur[s] = b_nxt[s];
           }
         }
+        if (tp == 0) T3_MARK(20 + ph);
+        if (tp == 1) T3_MARK(24 + ph);
       }
-      if (TAPS & 1) {       // odd number of visits: the prefetched operands of the next phase sit in set 1
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) aS[0][m][s] = aS[1][m][s];
-      }
+      T3_MARK(4 + 4 * ph);
     }
 
+    T3_MARK(17);
     // ---- epilogue: statistics of the tile, then the tile itself through LDS as whole rows ------------------------
     // sums about a pivot per (wave, row), merged with the counts at the end of the kernel (see stgcn_gcn3.hip)
     float *rs = rowstat + wave * 64 * T3_ST;
@@ -271,8 +347,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
           }
         }
     }
+    T3_MARK(18);
     {
       float *stg = lds + ((T3_NPH - 1) & 1) * BUF;          // main part of the last phase's buffer: free now
+      constexpr int R4 = RS / 4;                            // float4 per row (212)
+      constexpr int RIT = (R4 + 63) / 64;                   // 4
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -283,8 +362,6 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
 #pragma unroll
           for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
         }
-        constexpr int R4 = RS / 4;                          // float4 per row (212)
-        constexpr int RIT = (R4 + 63) / 64;                 // 4
         float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
         if (BWD) {   // the saved activation of this wave's two rows: in flight across the staging barrier
           const float4 *z4 = reinterpret_cast<const float4 *>(zg + (size_t)(16 * m + 2 * wave) * row_stride);
@@ -300,12 +377,12 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
         __builtin_amdgcn_s_barrier();
         float4 *orow = reinterpret_cast<float4 *>(og + (size_t)16 * m * row_stride);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
-        if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
+        if (BWD) {   // a wave takes two whole rows
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * wave + rr, c = 16 * m + row;
-            const float sc = aff[2 * c], sh = aff[2 * c + 1], mu = bstat[2 * c], is = bstat[2 * c + 1];
-            float s1 = 0.f, s2 = 0.f;
+            const float sc = aff[2 * c], sh = aff[2 * c + 1], mu = bstat[2 * c];
+            float s1 = bsum[m][rr][0], s2 = bsum[m][rr][1];
 #pragma unroll
             for (int it = 0; it < RIT; ++it) {
               const int c4 = it * 64 + lane;
@@ -316,19 +393,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
                 const float g0 = fmaf(zz.x, sc, sh) > 0.f ? v.x : 0.f, g1 = fmaf(zz.y, sc, sh) > 0.f ? v.y : 0.f;
                 const float g2 = fmaf(zz.z, sc, sh) > 0.f ? v.z : 0.f, g3 = fmaf(zz.w, sc, sh) > 0.f ? v.w : 0.f;
                 s1 += (g0 + g1) + (g2 + g3);
-                s2 = fmaf(g0, (zz.x - mu) * is, s2); s2 = fmaf(g1, (zz.y - mu) * is, s2);
-                s2 = fmaf(g2, (zz.z - mu) * is, s2); s2 = fmaf(g3, (zz.w - mu) * is, s2);
+                s2 = fmaf(g0, zz.x - mu, s2); s2 = fmaf(g1, zz.y - mu, s2);      // * invstd at the end of the kernel
+                s2 = fmaf(g2, zz.z - mu, s2); s2 = fmaf(g3, zz.w - mu, s2);
               }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-              s1 += __shfl_xor(s1, off, 64);
-              s2 += __shfl_xor(s2, off, 64);
-            }
-            if (lane == 0) {
-              rs[T3_ST * c] += s1;
-              rs[T3_ST * c + 1] += s2;
-            }
+            bsum[m][rr][0] = s1; bsum[m][rr][1] = s2;
           }
         } else {
 #pragma unroll
@@ -344,11 +413,31 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
         __builtin_amdgcn_s_barrier();
       }
     }
+    T3_MARK(19);
+  }
+  if (BWD) {
+    float *rs = rowstat + wave * 64 * T3_ST;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float s1 = bsum[m][rr][0], s2 = bsum[m][rr][1];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        const int c = 16 * m + 2 * wave + rr;
+        if (lane == 0) {
+          rs[T3_ST * c] = s1;
+          rs[T3_ST * c + 1] = s2 * bstat[2 * c + 1];
+        }
+      }
   }
 }
 
 template <bool XFORM, bool BWD, int TAPS>
-__global__ __launch_bounds__(T3_NW * 64, 2) void tconv3_kernel(
+__global__ __launch_bounds__(T3_NW * 64, 2) __attribute__((amdgpu_num_vgpr(224))) void tconv3_kernel(
     T3Params p, const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
     float *__restrict__ stats_partial, const float *__restrict__ bwd_z, const float *__restrict__ bwd_fin) {

@@ -202,8 +202,9 @@ def test_tconv3_equals_tconv2(dev, N, T, taps):
             a, b = outs
             if isinstance(a, tuple):
                 assert torch.equal(a[0], b[0])
-                if a[1].shape == b[1].shape:        # BatchNorm-backward sums: the same pairs
-                    assert torch.equal(a[1].sum(0), b[1].sum(0))
+                if a[1].shape == b[1].shape:        # BatchNorm-backward sums: the same pairs up to the summation order
+                    sa, sb = a[1].double().sum(0), b[1].double().sum(0)
+                    torch.testing.assert_close(sb, sa, rtol=2e-5, atol=2e-5 * float(sa.abs().max()))
                 else:                               # forward statistics: (sum, sum sq) against (count, mean, M2)
                     from pose2room_amd.p2rnet import bn_op
                     (m2, v2, _), (m3, v3, _) = bn_op.moments(a[1], N * T * V), bn_op.moments(b[1], N * T * V)

@@ -34,6 +34,10 @@ for taps in (3, 1):
         za, zb = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
         msg = f'taps {taps} {name:12s} tconv2 {res[False][1]:.3f} ms  tconv3 {res[True][1]:.3f} ms  equal {torch.equal(za, zb)}'
         if isinstance(a, tuple):
-            sa, sb = a[1].double().sum(0), b[1].double().sum(0)
+            from pose2room_amd.p2rnet import bn_op
+            if a[1].shape == b[1].shape:
+                sa, sb = a[1].double().sum(0), b[1].double().sum(0)
+            else:
+                sa, sb = bn_op.moments(a[1], N * T * V)[1], bn_op.moments(b[1], N * T * V)[1]
             msg += f'  stats rel err {((sa - sb).abs().max() / sa.abs().max()).item():.1e}'
         print(msg, flush=True)
