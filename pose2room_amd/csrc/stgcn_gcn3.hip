@@ -26,6 +26,18 @@
 
 #include "gcn3_sched.inc"
 
+// Cycle trace (profiling hook, off in the product build; see stgcn_tconv3.hip): -DP2R_CYCLE_TRACE, tools/dev_g3_trace.py
+#ifdef P2R_CYCLE_TRACE
+__device__ unsigned long long g3_trace[8 * 32];
+extern "C" int p2r_debug_g3_trace(unsigned long long *dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g3_trace), sizeof(g3_trace));
+}
+#define G3_TRACE_TILE(tile) const bool trace_on = blockIdx.x == 7 && (tile) == 7 + 3 * (int)gridDim.x
+#define G3_MARK(i) do { if (trace_on && lane == 0) g3_trace[wave * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G3_TRACE_TILE(tile)
+#define G3_MARK(i)
+#endif
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -244,6 +256,8 @@ __device__ __forceinline__ void g3_wave_main(
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * G3_F : 0;
     const float *nxg = x + (size_t)nseq * 64 * row_stride + (size_t)nt0 * V;
+    G3_TRACE_TILE(tile);
+    G3_MARK(0);
 
     // accumulators start from the bias table
 #pragma unroll
@@ -258,8 +272,11 @@ __device__ __forceinline__ void g3_wave_main(
 #pragma unroll 1
     for (int ph = 0; ph < G3_NPH; ++ph) {
       // slice `ph` has landed (every wave waited for its own pieces) and nobody reads the other buffer any more
+      G3_MARK(1 + 3 * ph);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      G3_MARK(2 + 3 * ph);
       __syncthreads();
+      G3_MARK(3 + 3 * ph);
       float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
       const char *xl = xl0 + (ph & 1) * BUF * sizeof(float);
       const bool copy = ph + 1 < G3_NPH || has_next;
@@ -281,6 +298,7 @@ __device__ __forceinline__ void g3_wave_main(
       }
     }
 
+    G3_MARK(13);
     // ---- epilogue: D[row = 16 m + 4 g + q][frame r] of joint sj[i]; statistics of the stored values.
     // The sums are taken about a pivot per (wave, row) -- the mean of the first 16 values the wave produces for the
     // row -- and merged at the end of the kernel with the counts (see bn_act.hip: sum v^2 - (sum v)^2 / n in fp32
@@ -312,6 +330,7 @@ __device__ __forceinline__ void g3_wave_main(
           }
         }
     }
+    G3_MARK(14);
     {
       // The tile leaves through LDS (see stgcn_gcn2.hip): the slice buffer of the last phase is free once every wave
       // has finished it; 16 rows at a time are laid out there as the tensor has them and written as whole
@@ -404,6 +423,7 @@ __device__ __forceinline__ void g3_wave_main(
         __builtin_amdgcn_s_barrier();
       }
     }
+    G3_MARK(15);
   }
 
 }

@@ -1,0 +1,50 @@
+"""Dev: cycle trace of one tile of gcn3_kernel: where do the cycles of a tile go, per wave?
+    make -C pose2room_amd/csrc clean all EXTRA=-DP2R_CYCLE_TRACE && python tools/dev_g3_trace.py   (then rebuild without)
+The stamps are s_memtime (shader clock cycles): 16 MFMAs = 512 cycles."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from pose2room_amd.p2rnet import gcn_op, gcn_tables
+from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+from pose2room_amd import _lib
+dev = torch.device('cuda:0')
+A = Graph().A
+K, V = A.shape[0], A.shape[1]
+tables = gcn_op.GraphTables(A)
+t = tables.on(dev)
+N, T = 32, 1024
+g = torch.Generator().manual_seed(0)
+x = torch.randn(N, 64, T, V, generator=g).to(dev)
+Wp = gcn_op.permute_planes((torch.randn(K, 64, 64, generator=g) / 8).to(dev))
+Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
+bias = torch.randn(64, V, generator=g).to(dev)
+add = torch.randn(N, 64, T, V, generator=g).to(dev)
+u = torch.randn(N, 64, T, V, generator=g).to(dev)
+mask = (torch.rand(N, 64, T, V, generator=g) > 0.4).to(torch.uint8).to(dev)
+fin = torch.randn(4, 64, generator=g).to(dev)
+cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+cases = {'forward+stats': dict(coef=cc, stream=t['stream_c'], bias_cv=bias, want_stats=True, form=0),
+         'dgrad': dict(coef=cr, stream=t['stream_r'], bias_cv=None, form=1),
+         'dgrad+bnbwd': dict(coef=cr, stream=t['stream_r'], bias_cv=None, addend=add, want_stats=True, bwd=(u, mask, fin), form=1)}
+names = {0: 'start', 13: 'mfma done', 14: 'stats done', 15: 'tile end'}
+for ph in range(4):
+    names[1 + 3 * ph] = f'ph{ph} end-of-prev'; names[2 + 3 * ph] = f'ph{ph} vm waited'; names[3 + 3 * ph] = f'ph{ph} barrier passed'
+order = list(range(16))
+for name, kw in cases.items():
+    kw = dict(kw)
+    coef, stream, bias_cv = kw.pop('coef'), kw.pop('stream'), kw.pop('bias_cv')
+    for _ in range(3):
+        gcn_op._gcn2_forward(x, Wp, coef, stream, bias_cv, tables, **kw)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 256)()
+    assert _lib.lib().p2r_debug_g3_trace(buf) == 0
+    tr = np.array(buf, dtype=np.int64).reshape(8, 32)
+    print(name)
+    for w in range(8):
+        prev = tr[w, 0]
+        line = []
+        for i in order:
+            line.append(f'{names[i]} +{tr[w, i] - prev}')
+            prev = tr[w, i]
+        print(f' wave {w}: total {tr[w, 15] - tr[w, 0]} cycles  ' + ' | '.join(line))
