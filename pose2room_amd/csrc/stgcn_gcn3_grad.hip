@@ -22,6 +22,18 @@
 
 #include "gcn3_sched.inc"
 
+// Cycle trace (profiling hook, off in the product build; see stgcn_tconv3.hip): -DP2R_CYCLE_TRACE, tools/dev_g3_trace.py
+#ifdef P2R_CYCLE_TRACE
+__device__ unsigned long long d3_trace[8 * 32];
+extern "C" int p2r_debug_d3_trace(unsigned long long *dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(d3_trace), sizeof(d3_trace));
+}
+#define D3_TRACE_TILE(tile) const bool trace_on = blockIdx.x == 7 && (tile) == 7 + 3 * (int)gridDim.x
+#define D3_MARK(i) do { if (trace_on && lane == 0) d3_trace[wave * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define D3_TRACE_TILE(tile)
+#define D3_MARK(i)
+#endif
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -214,9 +226,6 @@ __device__ __forceinline__ void d3_wave_main(const D3Params &p, float *lds, cons
     const int row = 4 * (lrow & 3) + (lrow >> 2);
     doff[i] = (pc < D3_PIECES && e < D3_NV4) ? (int)(((size_t)row * row_stride + 4 * c4) * sizeof(float)) : -1;
   }
-  // lane's element offsets of the B operands: channel 4 kk + g, frame r  (joint added per slot)
-  const size_t boff = (size_t)g * row_stride + (size_t)r * V;
-
   float bz[SLOTS][16];                                // X[4 kk + g][frame r][joint of the slot]
   float aS[2][16];                                    // two A-operand sets: W_k[16 p + r][4 kk + g], kk = 0..15
   f32x4 h;
@@ -241,42 +250,53 @@ __device__ __forceinline__ void d3_wave_main(const D3Params &p, float *lds, cons
 
   for (; tile < p.total_tiles; tile += gridDim.x) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * D3_F;
-    const float *xg = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V + boff;
     const float *dg = dz + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * D3_F : 0;
     const float *ndg = dz + (size_t)nseq * 64 * row_stride + (size_t)nt0 * V;
+    D3_TRACE_TILE(tile);
+    D3_MARK(0);
 
-    // B operands of the tile.  A wave's slots 0-3 hold a run of consecutive joints and so do its slots 4-6 (the
-    // schedule generator deals the joints that way), so one 16- or 12-byte load per lane and channel fetches a whole
-    // run: 32 load instructions per tile instead of 112, and a third of the 64-byte sectors (4-byte aligned vector
-    // loads; global memory takes them unaligned).
+    // B operands of the tile: X[4 kk + g][frame r][joint of the slot] for all 64 input channels, register-resident for
+    // the whole tile.  They come through LDS: buffer 1 is free between the last phase of one tile and the second of
+    // the next, and the four 16-channel slices of X pass through it one after the other as LDS-DMA pieces (whole
+    // 1 KB rows per instruction, the layout of the dZ slices: LDS row 4 g + kappa holds slice row 4 kappa + g), each
+    // read back with 28 immediate-offset ds_reads per lane.  Loaded straight from global memory (a 16- or 12-byte run
+    // of joints per lane and channel), a load instruction touched ~100 cache lines for 1 KB of data and the 32 of
+    // them per wave kept the address path of the CU busy for 15-37 thousand cycles per tile with nothing else to
+    // run (cycle trace, round 3).
     {
-      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-      typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
-      constexpr int na = (sj[0] >= 0) + (sj[1] >= 0) + (sj[2] >= 0) + (sj[3] >= 0);
-      constexpr int nb = (sj[4] >= 0) + (sj[5] >= 0) + (sj[6] >= 0);
-      static_assert(na >= 3 && nb == 3, "joint runs of the generated schedule");
+      float *xb = lds + BUF;
+      const char *xr = reinterpret_cast<const char *>(xb + 4 * g * RS + r * V);      // kappa = 0: + kappa * RS floats
+      const float *xs = x + (size_t)seq * 64 * row_stride + (size_t)t0 * V;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float *row = xg + (size_t)4 * kk * row_stride;
-        if (na == 4) {
-          const f4u u = *reinterpret_cast<const f4u *>(row + sj[0]);
-          bz[0][kk] = u.x; bz[1][kk] = u.y; bz[2][kk] = u.z; bz[3][kk] = u.w;
-        } else {
-          const f3u u = *reinterpret_cast<const f3u *>(row + sj[0]);
-          bz[0][kk] = u.x; bz[1][kk] = u.y; bz[2][kk] = u.z;
-        }
-        const f3u w = *reinterpret_cast<const f3u *>(row + sj[4]);
-        bz[4][kk] = w.x; bz[5][kk] = w.y; bz[6][kk] = w.z;
+      for (int sl = 0; sl < 4; ++sl) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                    // nobody reads buffer 1 any more
+#pragma unroll
+        for (int i = 0; i < D3_PW; ++i)
+          if (doff[i] >= 0) d3_dma16(xs + (size_t)sl * 16 * row_stride, doff[i], xb + (i * NW + wave) * 256);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i)
+          if (sj[i] >= 0) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp)
+              bz[i][4 * sl + kp] = *reinterpret_cast<const float *>(xr + (kp * RS + sj[i]) * 4);
+          }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the phase-0 barrier follows: buffer 1 is written next
     }
 
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
+      D3_MARK(1 + 3 * ph);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces of slice `ph` (and, first phase, the B operands)
+      D3_MARK(2 + 3 * ph);
       __syncthreads();
+      D3_MARK(3 + 3 * ph);
       float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
       const char *xl = xl0 + (ph & 1) * BUF * sizeof(float);
       const bool copy = ph + 1 < 4 || has_next;
@@ -289,6 +309,7 @@ __device__ __forceinline__ void d3_wave_main(const D3Params &p, float *lds, cons
       else if constexpr (WAVE == 4) { D3_BODY_4 } else if constexpr (WAVE == 5) { D3_BODY_5 }
       else if constexpr (WAVE == 6) { D3_BODY_6 } else { D3_BODY_7 }
     }
+    D3_MARK(13);
   }
 }
 

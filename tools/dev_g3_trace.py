@@ -48,3 +48,26 @@ for name, kw in cases.items():
             line.append(f'{names[i]} +{tr[w, i] - prev}')
             prev = tr[w, i]
         print(f' wave {w}: total {tr[w, 15] - tr[w, 0]} cycles  ' + ' | '.join(line))
+
+# adjacency-gradient kernel (csrc/stgcn_gcn3_grad.hip)
+dz = torch.randn(N, 64, T, V, generator=g).to(dev)
+ltot = cr.shape[0]
+part = torch.empty(256, ltot, V, device=dev)
+for _ in range(3):
+    _lib.check(_lib.lib().p2r_stgcn_gcn3_coef_grad(N, T, V, K, ltot, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(Wp), 256, _lib.ptr(part),
+                                                   _lib.current_stream(dev)), 'coef_grad')
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 256)()
+assert _lib.lib().p2r_debug_d3_trace(buf) == 0
+tr = np.array(buf, dtype=np.int64).reshape(8, 32)
+names = {0: 'start', 13: 'tile end'}
+for ph in range(4):
+    names[1 + 3 * ph] = f'ph{ph} end-of-prev'; names[2 + 3 * ph] = f'ph{ph} vm waited'; names[3 + 3 * ph] = f'ph{ph} barrier passed'
+print('coef_grad')
+for w in range(8):
+    prev = tr[w, 0]
+    line = []
+    for i in range(14):
+        line.append(f'{names[i]} +{tr[w, i] - prev}')
+        prev = tr[w, i]
+    print(f' wave {w}: total {tr[w, 13] - tr[w, 0]} cycles  ' + ' | '.join(line))
