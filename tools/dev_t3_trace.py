@@ -1,11 +1,12 @@
 """Dev: cycle trace of one tile of tconv3: where do the cycles of a tile go, per wave?
-    make -C pose2room_amd/csrc clean all EXTRA=-DP2R_CYCLE_TRACE && python tools/dev_t3_trace.py   (then rebuild without)
+    bash tools/build_trace_lib.sh && python tools/dev_t3_trace.py    (instrumented copy of the library: tools/ubench/libp2r_hip_trace.so)
 The stamps are s_memtime (shader clock cycles): 16 MFMAs = 512 cycles."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from pose2room_amd.p2rnet import tconv_op
 from pose2room_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libp2r_hip_trace.so")
 dev = torch.device('cuda:0')
 N, T, V = 32, 1024, 53
 g = torch.Generator().manual_seed(0)
