@@ -87,3 +87,18 @@ def test_static_schedule_is_in_sync_with_its_generator():
     body = '\n'.join(out)
     assert body in committed, "gcn3_sched.inc is stale: run python tools/gen_gcn_sched.py and rebuild"
     assert gcn_op.GraphTables(A).gen3
+
+
+def test_tconv3_reserved_registers_are_not_allocated_by_the_compiler():
+    """csrc/stgcn_tconv3.hip keeps its A-operand sets in v224..v255 by name and caps the compiler at v223 with
+    amdgpu_num_vgpr -- a target the allocator exceeds under pressure instead of spilling (round 3: a variant with 64
+    more live registers in the epilogue silently overwrote the operands of the next tile).  The assembly of the
+    committed source must not touch those registers outside the inline-assembly blocks."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('check_reserved_vgprs', os.path.join(root, 'tools', 'check_reserved_vgprs.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.offenders(os.path.join(root, 'pose2room_amd', 'csrc', 'stgcn_tconv3.hip'))
+    assert not bad, bad[:5]
