@@ -52,6 +52,11 @@ for name, kw in cases.items():
     err = (za - zb).abs().max().item() / za.abs().max().item()
     msg = f'{name:22s} gcn2 {res[False][1]:.3f} ms   gcn3 {res[True][1]:.3f} ms   z rel err {err:.2e}'
     if isinstance(a, tuple):
-        sa, sb = a[1].double().sum(0), b[1].double().sum(0)
+        if a[1].shape == b[1].shape:
+            sa, sb = a[1].double().sum(0), b[1].double().sum(0)
+        else:       # (sum, sum sq) pairs against (count, mean, M2) entries: compare the variances
+            from pose2room_amd.p2rnet import bn_op
+            M = x.shape[0] * x.shape[2] * x.shape[3]
+            sa, sb = bn_op.moments(a[1], M)[1], bn_op.moments(b[1], M)[1]
         msg += f'   stats rel err {((sa - sb).abs().max() / sa.abs().max()).item():.2e}'
     print(msg, flush=True)
