@@ -123,6 +123,16 @@ __device__ __forceinline__ void t3_mfma16(f32x4 (&acc)[4], const float (&b)[4]) 
       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
 
+// The 4 MFMAs of a quarter unit: one 16-row block MQ of one joint (see the joint assignment in t3_wave_main)
+template <int SET, int MQ>
+__device__ __forceinline__ void t3_mfma4(f32x4 &acc, const float (&b)[4]) {
+  constexpr int A0 = 224 + 16 * SET + 4 * MQ;
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_16x16x4_f32 %0, v[%5:%5], %1, %0\n\tv_mfma_f32_16x16x4_f32 %0, v[%6:%6], %2, %0\n\t"
+               "v_mfma_f32_16x16x4_f32 %0, v[%7:%7], %3, %0\n\tv_mfma_f32_16x16x4_f32 %0, v[%8:%8], %4, %0"
+               : "+v"(acc) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(A0), "n"(A0 + 1), "n"(A0 + 2), "n"(A0 + 3));
+}
+
 // XFORM: input transform relu(x * scale + shift) applied in place to each slice; BWD (data-gradient instance): the
 // statistics epilogue emits the two sums of the BatchNorm + ReLU backward of the layer in front (see stgcn_tconv2.hip).
 template <bool XFORM, bool BWD, int TAPS, int WAVE>
@@ -132,9 +142,15 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   constexpr int V = T3_V, NW = T3_NW, SLOTS = T3_SLOTS, RS = T3_RS, MAIN = T3_MAIN, HRS = T3_HRS, HALO = T3_HALO,
                 BUF = T3_BUF, NV4 = T3_NV4;
   constexpr int wave = WAVE;
-  // joints of this wave: consecutive runs 7,7,7,7,7,6,6,6 (waves w and w + 4 share a SIMD: 14,13,13,13 units per tap)
-  constexpr int j0 = WAVE < 5 ? 7 * WAVE : 35 + 6 * (WAVE - 5);
-  constexpr int nslots = WAVE < 5 ? 7 : 6;
+  // joints of this wave: consecutive runs 7,7,7,7,6,6,6,6 = joints 0..51; joint 52 is split by its four 16-row blocks
+  // over waves 4..7.  Waves w and w + 4 share a SIMD: 13.25 units per tap on each (with whole joints only, 53 joints
+  // over four SIMDs are 14,13,13,13 and three SIMDs idle 7 % of every phase: cycle trace, round 3)
+  constexpr int j0 = WAVE < 4 ? 7 * WAVE : 28 + 6 * (WAVE - 4);
+  constexpr int nslots = WAVE < 4 ? 7 : 6;
+  constexpr bool QUARTER = WAVE >= 4;                  // + row block MQ of joint 52
+  constexpr int MQ = WAVE >= 4 ? WAVE - 4 : 0;
+  constexpr int JQ = T3_V - 1;
+  constexpr int NU = nslots + (QUARTER ? 1 : 0);       // units per tap visit (the last one a quarter)
   constexpr int PW16 = T3_PW16, PWH = TAPS > 1 ? T3_PWH : 0;
   float *rowstat = lds + 2 * BUF;                     // [NW][64][T3_ST]
   float *aff = rowstat + NW * 64 * T3_ST;                  // [64][2] (scale, shift) of the input transform
@@ -194,6 +210,7 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   };
 
   f32x4 acc[SLOTS][4];
+  f32x4 accq = {0.f, 0.f, 0.f, 0.f};                   // QUARTER: rows 16 MQ .. 16 MQ + 15 of joint 52
   // A-operand sets: visit `tp` of a phase multiplies with set tp & 1 and loads the next visit's operands into the
   // other one; a phase ends with the next phase's first operands in set 1 (TAPS is odd), moved to set 0 once they
   // have arrived
@@ -235,6 +252,10 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[i][m][q] = bias_l[16 * m + 4 * g + q];
+    if (QUARTER) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) accq[q] = bias_l[16 * MQ + 4 * g + q];
+    }
 
 #pragma unroll 1
     for (int ph = 0; ph < T3_NPH; ++ph) {
@@ -296,17 +317,23 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
         }
         if (tp == 0 && copy) copy_slice(buf_nxt, src, slo, shi);
 #pragma unroll
-        for (int i = 0; i < nslots; ++i) {
-          // B operand of the next unit requested before this unit's MFMAs
-          const int ni = i + 1 < nslots ? i + 1 : 0, ntp2 = i + 1 < nslots ? tp : tp + 1;
+        for (int i = 0; i < NU; ++i) {
+          // B operand of the next unit requested before this unit's MFMAs (unit nslots, if any, is the quarter: joint 52)
+          const int ni = i + 1 < NU ? i + 1 : 0, ntp2 = i + 1 < NU ? tp : tp + 1;
+          const int nj = ni < nslots ? ni : JQ - j0;
           float b_nxt[4];
           if (ntp2 < TAPS) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b_nxt[s] = *reinterpret_cast<const float *>(bufc + rd[ntp2][s] + 4 * ni);
+            for (int s = 0; s < 4; ++s) b_nxt[s] = *reinterpret_cast<const float *>(bufc + rd[ntp2][s] + 4 * nj);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (tp & 1) t3_mfma16<1>(acc[i], b_cur);
-          else t3_mfma16<0>(acc[i], b_cur);
+          if (i < nslots) {
+            if (tp & 1) t3_mfma16<1>(acc[i < nslots ? i : 0], b_cur);
+            else t3_mfma16<0>(acc[i < nslots ? i : 0], b_cur);
+          } else {
+            if (tp & 1) t3_mfma4<1, MQ>(accq, b_cur);
+            else t3_mfma4<0, MQ>(accq, b_cur);
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (ntp2 < TAPS) {
 #pragma unroll
@@ -338,6 +365,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
             s1 += v;
             s2 = fmaf(v, v, s2);
           }
+          if (QUARTER && m == MQ) {
+            const float v = accq[q] - c;
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
           s1 = p2r_row16_sum(s1);
           s2 = p2r_row16_sum(s2);
           if (r == 0) {
@@ -361,6 +393,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
           float *d0 = stg + 4 * g * RS + r * V + j0 + i;
 #pragma unroll
           for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
+        }
+        if (QUARTER && m == MQ) {
+          float *d0 = stg + 4 * g * RS + r * V + JQ;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) d0[q * RS] = accq[q];
         }
         float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
         if (BWD) {   // the saved activation of this wave's two rows: in flight across the staging barrier
@@ -485,7 +522,8 @@ __global__ __launch_bounds__(T3_NW * 64, 2) __attribute__((amdgpu_num_vgpr(224))
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
         const float *e = rowstat + (w * 64 + tid) * T3_ST;
-        nw[w] = per_joint * (float)(w < 5 ? 7 : 6);       // joints per wave: see t3_wave_main
+        // joints per (wave, row): see t3_wave_main (waves 4..7 own row block w - 4 of joint 52 on top of their six)
+        nw[w] = per_joint * (float)(w < 4 ? 7 : 6 + ((tid >> 4) == w - 4 ? 1 : 0));
         const float d = e[0] / nw[w];
         mw[w] = e[2] + d;
         qw[w] = fmaxf(e[1] - e[0] * d, 0.f);
