@@ -384,6 +384,20 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
       float *stg = lds + ((T3_NPH - 1) & 1) * BUF;          // main part of the last phase's buffer: free now
       constexpr int R4 = RS / 4;                            // float4 per row (212)
       constexpr int RIT = (R4 + 63) / 64;                   // 4
+      // BWD: the saved activation of the two rows this wave stores in a round.  A row's buffer is reloaded for the next
+      // round as soon as the row has been processed -- the loads then have the rest of the round, its closing barrier
+      // and the next staging to arrive, instead of being issued right in front of the barrier they are needed behind --
+      // at no cost in registers.
+      float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
+      auto load_z = [&](int m, int rr) {
+        const float4 *z4 = reinterpret_cast<const float4 *>(zg + (size_t)(16 * m + 2 * wave + rr) * row_stride);
+#pragma unroll
+        for (int it = 0; it < (BWD ? RIT : 1); ++it) {
+          const int c4 = it * 64 + lane;
+          zv[BWD ? rr : 0][it] = c4 < R4 ? z4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      if (BWD) { load_z(0, 0); load_z(0, 1); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -398,17 +412,6 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
           float *d0 = stg + 4 * g * RS + r * V + JQ;
 #pragma unroll
           for (int q = 0; q < 4; ++q) d0[q * RS] = accq[q];
-        }
-        float4 zv[BWD ? 2 : 1][BWD ? RIT : 1];
-        if (BWD) {   // the saved activation of this wave's two rows: in flight across the staging barrier
-          const float4 *z4 = reinterpret_cast<const float4 *>(zg + (size_t)(16 * m + 2 * wave) * row_stride);
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-              const int c4 = it * 64 + lane;
-              zv[rr][it] = c4 < R4 ? z4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -435,6 +438,7 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
               }
             }
             bsum[m][rr][0] = s1; bsum[m][rr][1] = s2;
+            if (m + 1 < 4) load_z(m + 1, rr);
           }
         } else {
 #pragma unroll
