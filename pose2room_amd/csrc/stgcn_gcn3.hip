@@ -336,6 +336,28 @@ __device__ __forceinline__ void g3_wave_main(
       // has finished it; 16 rows at a time are laid out there as the tensor has them and written as whole
       // 16-byte-per-lane rows.  LDS-only waits in front of the barriers: the global stores stay in flight.
       float *stg = lds + ((G3_NPH - 1) & 1) * BUF;
+      constexpr int R4 = RS / 4;                            // float4 per row (212)
+      constexpr int RIT = (R4 + 63) / 64;                   // 4
+      // BWD: saved activation, mask bytes and addend of the two rows this wave stores in a round.  A row's buffers are
+      // reloaded for the next round as soon as the row has been processed (see stgcn_tconv3.hip): the loads then have
+      // the rest of the round, its closing barrier and the next staging to arrive.
+      float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
+      float4 ad[BWD ? 2 : 1][BWD ? RIT : 1];
+      unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
+      auto load_bwd = [&](int m, int rr) {
+        const size_t r0 = (size_t)(16 * m + 2 * wave + rr) * row_stride;
+        const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
+        const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
+        const float4 *a4 = reinterpret_cast<const float4 *>(ag ? ag + r0 : nullptr);
+#pragma unroll
+        for (int it = 0; it < (BWD ? RIT : 1); ++it) {
+          const int c4 = it * 64 + lane;
+          uv[BWD ? rr : 0][it] = c4 < R4 ? u4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          mk[BWD ? rr : 0][it] = c4 < R4 ? m4[c4] : 0u;
+          if (a4 && c4 < R4) ad[BWD ? rr : 0][it] = a4[c4];
+        }
+      };
+      if (BWD) { load_bwd(0, 0); load_bwd(0, 1); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -347,26 +369,6 @@ __device__ __forceinline__ void g3_wave_main(
 #pragma unroll
             for (int q = 0; q < 4; ++q) d0[q * RS] = acc[i][m][q];
           }
-        constexpr int R4 = RS / 4;                          // float4 per row (212)
-        constexpr int RIT = (R4 + 63) / 64;                 // 4
-        float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
-        float4 ad[BWD ? 2 : 1][BWD ? RIT : 1];
-        unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
-        if (BWD) {   // saved activation, mask bytes and addend of this wave's two rows: in flight across the staging barrier
-          const size_t r0 = (size_t)(16 * m + 2 * wave) * row_stride;
-          const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
-          const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
-          const float4 *a4 = reinterpret_cast<const float4 *>(ag ? ag + r0 : nullptr);
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-              const int c4 = it * 64 + lane;
-              uv[rr][it] = c4 < R4 ? u4[(size_t)rr * (row_stride / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-              mk[rr][it] = c4 < R4 ? m4[(size_t)rr * (row_stride / 4) + c4] : 0u;
-              if (a4 && c4 < R4) ad[rr][it] = a4[(size_t)rr * (row_stride / 4) + c4];
-            }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
@@ -403,6 +405,7 @@ __device__ __forceinline__ void g3_wave_main(
               rs[G3_ST * c] += s1;
               rs[G3_ST * c + 1] += s2;
             }
+            if (m + 1 < 4) load_bwd(m + 1, rr);
           }
         } else {
 #pragma unroll
