@@ -176,7 +176,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
 // dW[p][c][ci] = sum_{n,t,w} dout[n,c,t,w] * h[n,ci,t+p-1,w]   (h as above)
 // persistent grid; wave = (ci tile nt = wave&3, row group mh = wave>>2): TAPS planes x TW_MT row
 // tiles of accumulators; reduction steps of 4 consecutive columns.
-constexpr int TW_F = 4;
+constexpr int TW_F = 4;            // frames per tile; the single-tap launch for 20 columns per frame (the position-embedding MLP) uses 12: see p2r_stgcn_tconv_weight_grad
 #define TW_WAVES 16   // four waves per SIMD: same time as 8 for the 3-tap form, -15 % for the single-tap form
 constexpr int TW_THREADS = 64 * TW_WAVES;
 constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves = 4 ci tiles x TW_WAVES/4 row groups)
@@ -184,7 +184,7 @@ constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves 
 // VS = compile-time joint count (0: run time).  With VS fixed the reduction loop is fully unrolled and every
 // LDS read carries an immediate offset: no address arithmetic on the VALU, which on gfx950 does not overlap
 // with the partner waves' MFMAs.
-template <int TAPS, int VS>
+template <int TAPS, int VS, int F = TW_F>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int nt = wave & 3, mh = wave >> 2;          // 16 ci columns x (64 / TW_MH) c rows per wave
-  const int tiles_per_seq = (T + TW_F - 1) / TW_F;
+  const int tiles_per_seq = (T + F - 1) / F;
   const int total_tiles = n_seq * tiles_per_seq;
   const size_t row_stride = (size_t)T * V;
 
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   float ph_[NR][NH], pd_[NR][4];
   auto issue_loads = [&](int tile) {
     const int seq = tile / tiles_per_seq;
-    const int t0 = (tile % tiles_per_seq) * TW_F;
-    const int frames = min(TW_F, T - t0);
+    const int t0 = (tile % tiles_per_seq) * F;
+    const int frames = min(F, T - t0);
     const int ncols = frames * V;
     const float *xg = x + (size_t)seq * TC_C * row_stride;
     const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
 #pragma unroll
     for (int m = 0; m < TW_MT; ++m) a[m] = drow[16 * m * row_d];
     if constexpr (VS > 0) {
-      constexpr int STEPS = (TW_F * VS + 3) / 4;
+      constexpr int STEPS = (F * VS + 3) / 4;
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * VS];
 #pragma unroll
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
         for (int p = 0; p < TAPS; ++p) b[p] = nb[p];
       }
     } else {
-      const int steps = (TW_F * V + 3) / 4;
+      const int steps = (F * V + 3) / 4;
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * V];
       for (int s = 0; s < steps; ++s) {
@@ -388,23 +388,23 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const floa
                    : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream);
 }
 
-template <int TAPS, int VS>
+template <int TAPS, int VS, int F = TW_F>
 static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
                            void *stream) {
   constexpr int HALO = (TAPS - 1) / 2;
-  int row_d = TW_F * V + 7;                      // room for the last (partial) 4-column step + one prefetched step
+  int row_d = F * V + 7;                      // room for the last (partial) 4-column step + one prefetched step
   while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
-  int row_h = (TW_F + 2 * HALO) * V + 7;
+  int row_h = (F + 2 * HALO) * V + 7;
   while (row_h % 32 != 2) ++row_h;
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
-  if (lds > 160 * 1024 || TW_F * V > 256 || (TW_F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
+  if (lds > 160 * 1024 || F * V > 256 || (F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
-    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS>, lds_ok);
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F>, lds_ok);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
+  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
                      row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
@@ -417,6 +417,11 @@ extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const 
                                            float *dw_partial, float *dbias_partial, void *stream) {
   if (N < 0 || T <= 0 || V <= 0 || V > 64 || n_blocks < 1 || (taps != 1 && taps != 3)) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
+  // 20 columns per frame, one tap: the 64 -> 64 layers of the position-embedding MLP (stgcn.py:46-63, knn = 20).  A
+  // 4-frame tile is 20 reduction steps there -- less work than the staging and the two barriers around it -- so this
+  // shape gets 12-frame tiles (60 steps, 123 KB of LDS) and its own fully unrolled instance.
+  if (V == 20 && taps == 1)
+    return tconv_dw_launch<1, 20, 12>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
   if (V == 53)   // the P2RNet skeleton: fully unrolled reduction loop
     return taps == 3
                ? tconv_dw_launch<3, 53>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
