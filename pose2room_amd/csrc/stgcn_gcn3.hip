@@ -307,26 +307,31 @@ __device__ __forceinline__ void g3_wave_main(
     if (!BWD && want_stats) {
       constexpr int I0 = g3_first_slot(FORM, WAVE);
       const bool first = tile == (int)blockIdx.x;
+      // two rows (q, q + 1) per instruction: the accumulator tile is four consecutive registers, so the differences,
+      // sums and squares of a pair are one packed instruction each (VALU time is matrix-pipe time: half the count)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float *e = rs + G3_ST * (16 * m + 4 * g + q);
-          const float c = first ? p2r_row16_sum(acc[I0][m][q]) * 0.0625f : e[2];
-          float s1 = 0.f, s2 = 0.f;
+        for (int qp = 0; qp < 2; ++qp) {
+          float *e0 = rs + G3_ST * (16 * m + 4 * g + 2 * qp), *e1 = e0 + G3_ST;
+          f32x2 c;
+          c.x = first ? p2r_row16_sum(acc[I0][m][2 * qp]) * 0.0625f : e0[2];
+          c.y = first ? p2r_row16_sum(acc[I0][m][2 * qp + 1]) * 0.0625f : e1[2];
+          f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < SLOTS; ++i)
             if (sj[i] >= 0) {
-              const float v = acc[i][m][q] - c;
+              const f32x2 v = f32x2{acc[i][m][2 * qp], acc[i][m][2 * qp + 1]} - c;
               s1 += v;
-              s2 = fmaf(v, v, s2);
+              s2 = __builtin_elementwise_fma(v, v, s2);
             }
-          s1 = p2r_row16_sum(s1);
-          s2 = p2r_row16_sum(s2);
-          if (r == 0) {             // entry owned by (wave, row): plain read-modify-write, deterministic
-            e[0] += s1;
-            e[1] += s2;
-            if (first) e[2] = c;
+          const float s1x = p2r_row16_sum(s1.x), s1y = p2r_row16_sum(s1.y);
+          const float s2x = p2r_row16_sum(s2.x), s2y = p2r_row16_sum(s2.y);
+          if (r == 0) {             // entries owned by (wave, row): plain read-modify-write, deterministic
+            e0[0] += s1x; e0[1] += s2x;
+            e1[0] += s1y; e1[1] += s2y;
+            if (first) { e0[2] = c.x; e1[2] = c.y; }
           }
         }
     }
