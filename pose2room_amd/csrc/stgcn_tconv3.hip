@@ -271,19 +271,24 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
       const bool slo = same ? t0 > 0 : nt0 > 0, shi = same ? t0 + T3_F < p.T : nt0 + T3_F < p.T;
       if (XFORM) {
         // BatchNorm affine + ReLU once per element, in place in the slice that has just landed
+        // 32 threads per channel row (16 rows x 32 = the workgroup), 7 float4 each at a stride of 32: the row's
+        // constants are read once and the addresses are immediates of one base (a thread walking the slice linearly
+        // crossed rows: a division and two constant reads per float4)
         float *cur = lds + (ph & 1) * BUF;
-        float4 *cur4 = reinterpret_cast<float4 *>(cur);
+        {
+          const int row = tid >> 5, col = tid & 31;
+          const int ch = T3_CP * ph + row;
+          const float sc = aff[2 * ch], sh = aff[2 * ch + 1];
+          float4 *rp = reinterpret_cast<float4 *>(cur + row * RS) + col;
+          constexpr int R4 = RS / 4;                      // 212 float4 per row
 #pragma unroll
-        for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
-          const int e = it * NW * 64 + tid;
-          if (e < NV4) {
-            const int ch = T3_CP * ph + e / (RS / 4);
-            const float sc = aff[2 * ch], sh = aff[2 * ch + 1];
-            float4 v = cur4[e];
-            v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-            cur4[e] = v;
-          }
+          for (int it = 0; it < (R4 + 31) / 32; ++it)
+            if (32 * it + 31 < R4 || 32 * it + col < R4) {
+              float4 v = rp[32 * it];
+              v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+              v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+              rp[32 * it] = v;
+            }
         }
         if (TAPS > 1)
           for (int e = tid; e < HALO; e += NW * 64) {
