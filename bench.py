@@ -251,6 +251,15 @@ def verify_bench_shape(trainer, batch):
         worst = max(worst, err)
         assert err <= 1e-3, f'{k} of sample 0: batched vs alone differ by {err:.2e} of range'
     same = torch.equal(full['aggregated_vote_inds'][:1], one['aggregated_vote_inds'])
+    # Exact part, asserted: the proposal indices are a function of the sample's own votes -- FPS of sample 0's votes run
+    # alone reproduces the batch's indices bit for bit, and the two runs can only pick different proposals when their
+    # (fp32, differently batched GEMM) vote coordinates differ somewhere.  `aggregated_vote_inds_equal` then reports
+    # whether such a rounding difference flipped a discrete choice in this run (never observed at this shape).
+    from pose2room_amd.pointnet2_ops import _ext
+    alone = torch.sort(_ext.furthest_point_sampling(full['vote_xyz'][:1].contiguous(), full['aggregated_vote_inds'].shape[1]).long(), dim=-1)[0]
+    assert torch.equal(alone, full['aggregated_vote_inds'][:1]), 'FPS of sample 0 depends on the rest of the batch'
+    assert same or not torch.equal(full['vote_xyz'][:1], one['vote_xyz']), \
+        'identical votes gave different proposal indices'
     return {'losses_finite': True, 'seed_inds_equal': True, 'max_rel_err_sample0': float(f'{worst:.2e}'),
             'aggregated_vote_inds_equal': bool(same)}
 

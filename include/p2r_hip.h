@@ -34,7 +34,7 @@ extern "C" {
 #define P2R_EINVAL (-22)
 
 /* Library / build identification (sanity check for loaders). */
-int p2r_abi_version(void);          /* currently 1 */
+int p2r_abi_version(void);          /* currently 2; 1 = rounds 1-2 (p2r_bn_finalize without `width`, two-entry statistics partials) */
 const char *p2r_build_arch(void);   /* "gfx950" */
 
 /* ---- pointnet2_ops._ext: the nine reference launchers ------------------ */

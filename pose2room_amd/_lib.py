@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libp2r_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "p2r_hip.h")
 
+ABI_VERSION = 2     # p2r_abi_version() of the library this loader was written against (include/p2r_hip.h)
+
 _lib = None
 
 
@@ -40,8 +42,9 @@ def lib():
             raise P2RLibraryError(f"cannot load {LIB_PATH}: {e}") from e
         l.p2r_abi_version.restype = ctypes.c_int
         l.p2r_build_arch.restype = ctypes.c_char_p
-        if l.p2r_abi_version() != 1:
-            raise P2RLibraryError("libp2r_hip.so ABI version mismatch")
+        if l.p2r_abi_version() != ABI_VERSION:
+            raise P2RLibraryError(f"libp2r_hip.so ABI version {l.p2r_abi_version()} != {ABI_VERSION}: stale library, rebuild it "
+                                  "(make -C pose2room_amd/csrc)")
         for name in declared_symbols():
             fn = getattr(l, name)
             if name == "p2r_stgcn_gcn3_signature":

@@ -25,7 +25,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_identity():
     l = _lib.lib()
-    assert l.p2r_abi_version() == 1
+    assert l.p2r_abi_version() == _lib.ABI_VERSION == 2
     assert l.p2r_build_arch() == b"gfx950"
 
 
@@ -63,42 +63,36 @@ def test_ops_refuse_cpu_tensors():
         nn_distance(torch.zeros(1, 2, 3), torch.zeros(1, 4, 3))
 
 
+def _tool(name):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, 'tools', name + '.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def test_static_schedule_is_in_sync_with_its_generator():
     """csrc/gcn3_sched.inc (committed, compiled into the library) must be what tools/gen_gcn_sched.py generates from
     the skeleton in stgcn_layers.Graph, and the library's pattern signatures must equal those of the run-time tables
-    -- otherwise the statically scheduled kernels would silently never be taken (GraphTables.gen3 False)."""
-    import importlib.util
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location('gen_gcn_sched', os.path.join(root, 'tools', 'gen_gcn_sched.py'))
-    gen = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(gen)
-    from pose2room_amd.p2rnet import gcn_tables, gcn_op
-    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
-    A = Graph().A
-    out = []
-    for form, tr in ((0, False), (1, True)):
-        nbr, gidx, Lk = gcn_tables.build(A, transpose=tr)
-        gen.emit_form(form, nbr, gidx, Lk, out)
-        if form == 1:
-            gen.emit_coef_grad(nbr, gidx, Lk, out)
-            gen.emit_weight_grad(nbr, gidx, Lk, out)
-    committed = open(os.path.join(root, 'pose2room_amd', 'csrc', 'gcn3_sched.inc')).read()
-    body = '\n'.join(out)
-    assert body in committed, "gcn3_sched.inc is stale: run python tools/gen_gcn_sched.py and rebuild"
-    assert gcn_op.GraphTables(A).gen3
+    -- otherwise the statically scheduled kernels would silently never be taken (GraphTables.gen3 False).  The same
+    check runs in `__graft_entry__.build()`."""
+    _tool('check_build').check_schedule_sync()
 
 
-def test_tconv3_reserved_registers_are_not_allocated_by_the_compiler():
+def test_reserved_register_check_is_part_of_the_build():
     """csrc/stgcn_tconv3.hip keeps its A-operand sets in v224..v255 by name and caps the compiler at v223 with
     amdgpu_num_vgpr -- a target the allocator exceeds under pressure instead of spilling (round 3: a variant with 64
-    more live registers in the epilogue silently overwrote the operands of the next tile).  The assembly of the
-    committed source must not touch those registers outside the inline-assembly blocks."""
-    import importlib.util
-    import os
+    more live registers in the epilogue silently overwrote the operands of the next tile).  The Makefile compiles
+    every source that names registers to assembly with ITS flags and refuses to link on an offender; here: the stamp
+    exists for the library under test, the checker finds the named registers, and it does flag a register the
+    compiler uses."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location('check_reserved_vgprs', os.path.join(root, 'tools', 'check_reserved_vgprs.py'))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    bad = mod.offenders(os.path.join(root, 'pose2room_amd', 'csrc', 'stgcn_tconv3.hip'))
-    assert not bad, bad[:5]
+    csrc = os.path.join(root, 'pose2room_amd', 'csrc')
+    assert '$(CHECK)' in open(os.path.join(csrc, 'Makefile')).read()
+    stamp = os.path.join(csrc, '.reserved_vgprs.ok')
+    assert os.path.exists(stamp), 'libp2r_hip.so was linked without the reserved-register check'
+    chk = _tool('check_reserved_vgprs')
+    assert chk.named_registers(os.path.join(csrc, 'stgcn_tconv3.hip')) == set(range(224, 256))
+    assert chk.named_registers(os.path.join(csrc, 'ball_query.hip')) == set()
+    assert chk.offenders(os.path.join(csrc, 'ball_query.hip'), reserved={0, 1}), "the checker must see compiler-used registers"
