@@ -438,6 +438,108 @@ int p2r_sa_votes_backward(int b, int m, int nsample, int C, const float *dout, c
 int p2r_gemm_nt_256(int nb, int L, int split, const float *A, const float *B, float *partial,
                     void *stream);
 
+
+/* ---- point-wise (kernel size 1) convolution stacks of the vote / proposal heads ------------------
+ *
+ * replaces the `SingleConv` chains ('cbr' = Conv1d(k=1, no bias) -> BatchNorm1d -> ReLU, 'c' = Conv1d(k=1) with bias) of
+ * CenterVoteModule.conv_input (models/p2rnet/modules/vote_center.py:28-48), ProposalNet.conv_center / conv_heading /
+ * conv_size / conv_sem_obj (proposal_net.py:77-95,183-191) and the mixture heads' backbone + pi convolutions
+ * (mdn.py:20-27,141-161) -- in the reference one cuDNN conv + one BatchNorm + one ReLU launch per layer forward and
+ * five or more backward.  Here a layer is ONE launch each way, and independent layers of equal depth (the four
+ * stems, the three mixture heads) share a launch as a JOB LIST.  Activations are (B, C, L) fp32 ("NCL", the Conv1d
+ * layout) or (B, L, C) ("NLC", what `transpose(1, 2)` of it looks like in memory); L % 64 == 0.
+ *
+ * The BatchNorm + ReLU of layer i is never materialised: layer i+1 applies it to its input tile as it stages the
+ * tile into LDS (forward: relu(z * scale + shift); backward: the gradient of the pre-BatchNorm output is formed the
+ * same way as a*g + b*z + c from the stored masked gradient g, the stored conv output z and three per-channel
+ * constants).  Batch statistics leave the forward kernel as (count, mean, M2) entries per 64-column tile, the two
+ * BatchNorm-backward sums leave the data-gradient kernel per tile; one small multi-job launch finalises either.
+ *
+ * All structs are plain C; every pointer is a device pointer; arrays of jobs are HOST arrays (copied into the kernel
+ * arguments), at most P2R_PW_MAX_JOBS per call. */
+#define P2R_PW_MAX_JOBS 8
+
+/* out[rows x cols] = op(W)[rows x k] . T(x)[k x cols]  (+ epilogue), one job of p2r_pw_gemm.
+ *   x, x2 : the k-row input.  T = identity (tr == NULL), relu(x * tr[0][c] + tr[1][c]) (tr_mode 1: forward through a
+ *           BatchNorm + ReLU), or tr[0][c] * x + tr[1][c] * x2 + tr[2][c] (tr_mode 2: the BatchNorm-backward form;
+ *           x = masked gradient, x2 = saved conv output).  tr rows are `tr_ld` floats apart.
+ *           x_ctot = channels of the tensor x (and x2) points INTO (the pointer is already offset to this job's
+ *           first channel); x_nlc != 0: (B, L, x_ctot) memory, k % 4 == 0 then.
+ *   w     : w_t == 0: [rows][k] row-major (a Conv1d weight, forward); w_t != 0: [k][rows] (the same weight read
+ *           transposed: data gradient).
+ *   bias  : [rows] or NULL.
+ *   out   : NCL (out_nlc == 0) or NLC, out_ctot channels in the tensor, pointer pre-offset.
+ *   epilogue 0: out = acc (+ bias).  stats != NULL: (count, mean, M2) of every output row over the 64-column tile
+ *               -> stats [cols/64][rows][3].
+ *   epilogue 1 (data gradient through the ReLU + BatchNorm in front): m = mz * mfin[2][r] + mfin[3][r] > 0,
+ *               out = m ? acc : 0; stats [cols/64][rows][2] = (sum out, sum out * (mz - mfin[0][r]) * mfin[1][r]).
+ *               mz: NCL with mz_ctot channels; mfin rows `mfin_ld` floats apart. */
+typedef struct p2r_pw_job {
+  const float *x, *x2, *tr, *w, *bias, *mz, *mfin;
+  float *out, *stats;
+  int k, rows, x_ctot, x_nlc, tr_mode, tr_ld, w_t, out_ctot, out_nlc, epilogue, mz_ctot, mfin_ld;
+} p2r_pw_job;
+
+/* njobs jobs over the same B x L columns; one workgroup per (job, 64-column tile). */
+int p2r_pw_gemm(int njobs, const p2r_pw_job *jobs, int B, int L, void *stream);
+
+/* weight (+ bias) gradient of one layer: dw_part [split][rows][k] partials of  sum_cols T(dz)[rows] * U(y)[k]^T,
+ * db_part [split][rows] partials of the row sums of T(dz) (or NULL).  dz side: x / x2 / tr / tr_mode as above
+ * (tr_mode 0 or 2); y side: y, ytr [2][k] (NULL or relu(y * ytr[0] + ytr[1])), rows `ytr_ld` apart. */
+typedef struct p2r_pw_wjob {
+  const float *x, *x2, *tr, *y, *ytr;
+  float *dw_part, *db_part;
+  int rows, k, x_ctot, x_nlc, tr_mode, tr_ld, y_ctot, y_nlc, ytr_ld, split;
+} p2r_pw_wjob;
+int p2r_pw_wgrad(int njobs, const p2r_pw_wjob *jobs, int B, int L, void *stream);
+
+/* BatchNorm1d statistics of a job list.  part [P][C][3] (count, mean, M2) from p2r_pw_gemm, or NULL = evaluation
+ * mode (running statistics).  fin: mean, invstd, scale = gamma * invstd, shift = beta - mean * scale at
+ * fin[i * fin_ld + c].  Training (part != NULL, momentum >= 0): running_mean / running_var / num_batches_tracked
+ * updated as nn.BatchNorm1d does (unbiased variance). */
+typedef struct p2r_pw_bnjob {
+  const float *part, *gamma, *beta;
+  float *running_mean, *running_var, *fin;
+  long long *num_batches_tracked;
+  double eps, momentum;
+  int P, C, fin_ld;
+} p2r_pw_bnjob;
+int p2r_pw_bn_finalize(int njobs, const p2r_pw_bnjob *jobs, void *stream);
+
+/* BatchNorm1d backward constants.  part [P][C][2] = (sum g, sum g * xhat) from p2r_pw_gemm (epilogue 1);
+ * dgamma = sum g * xhat, dbeta = sum g; coef (rows coef_ld apart) = a, b, c with  dz = a*g + b*z + c:
+ * training  a = scale, b = -scale * invstd * m2, c = -scale * m1 + scale * invstd * m2 * mean  (m = sums / M);
+ * evaluation-mode BatchNorm (train == 0)  a = scale, b = c = 0. */
+typedef struct p2r_pw_bnbjob {
+  const float *part, *fin;
+  float *coef, *dgamma, *dbeta;
+  double M;
+  int P, C, fin_ld, coef_ld, train;
+} p2r_pw_bnbjob;
+int p2r_pw_bn_bwd_finalize(int njobs, const p2r_pw_bnbjob *jobs, void *stream);
+
+/* out[j] = sum_p in[p * M + j]  for every job (partials of p2r_pw_wgrad and the like), pairwise-ordered, deterministic. */
+typedef struct p2r_pw_rjob {
+  const float *in;
+  float *out;
+  int P, M;
+} p2r_pw_rjob;
+#define P2R_PW_MAX_RJOBS 48
+int p2r_pw_reduce(int njobs, const p2r_pw_rjob *jobs, void *stream);
+
+/* Mixture-density read-out (mdn.py:34-83, MixtureDensityHead.generate_point_predictions with n_samples = 1 and
+ * the mixture weights as gates): pred[b, l, d] = sum_g sigmoid(logit[b, g, l]) * (mu[g, d] + exp(log_sigma[g, d]) *
+ * eps[(b * L + l), g, d]).  logit (B, G, L) f32 inside a tensor of logit_ctot channels; mu / eps / pred are f32
+ * (f64 == 0) or f64 (the heading head, whose `mu` is a float64 parameter); log_sigma f32; eps == NULL: the mixture
+ * mean (get_mean, mdn.py:85-99).  pi (B, G, L) f32 optional output.  D <= 4. */
+int p2r_mdn_mix_forward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot, const void *mu,
+                        const float *log_sigma, const void *eps, void *pred, float *pi, void *stream);
+/* its gradient: dpred (B, L, D) -> dlogit (B, G, L) f32 (inside a tensor of dlogit_ctot channels), dmu [G][D]
+ * (f32 / f64 like mu), dlog_sigma [G][D] f32; one workgroup per component g. */
+int p2r_mdn_mix_backward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot, const void *mu,
+                         const float *log_sigma, const void *eps, const void *dpred, float *dlogit, int dlogit_ctot,
+                         void *dmu, float *dlog_sigma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

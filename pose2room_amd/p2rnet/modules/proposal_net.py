@@ -15,6 +15,9 @@ from .mdn import CategoryEmbeddingMDN
 from .sub_modules import SingleConv
 
 
+USE_FUSED_HEADS = True      # tests switch it off to reach the module chain (nn.Conv1d / nn.BatchNorm1d)
+
+
 def decode_scores(pred_center, pred_size, pred_heading, sem_obj_feature, end_points):
     """(B,D,K) head outputs -> end_points entries in (B,K,D) layout (proposal_net.py:15-34)."""
     sem_obj = sem_obj_feature.transpose(2, 1)
@@ -152,20 +155,31 @@ class ProposalNet(nn.Module):
         of explicit mixture noise (see mdn.py)."""
         features = self._aggregate(xyz, features, end_points)
         eps = eps or {}
-        pred_center = self.gmm_center.predict(self.conv_center(features), eps=eps.get('center'))
-        pred_size = self.gmm_size.predict(self.conv_size(features), eps=eps.get('size'))
-        pred_heading = self.gmm_heading.predict(self.conv_heading(features), eps=eps.get('heading'))
-        sem_obj_feature = self.conv_sem_obj(features)
+        from .. import pw_op
+        if USE_FUSED_HEADS and pw_op.proposal_heads_supported(self, features):
+            # the four stems, the mixture backbones / pi convolutions / read-outs and conv_sem_obj on the job-list
+            # kernels of csrc/pw_layers.hip (10 launches; same parameters, same noise draws in the same order)
+            pred_center, pred_size, pred_heading, sem_obj_feature = pw_op.proposal_heads(self, features, eps)
+        else:
+            pred_center = self.gmm_center.predict(self.conv_center(features), eps=eps.get('center'))
+            pred_size = self.gmm_size.predict(self.conv_size(features), eps=eps.get('size'))
+            pred_heading = self.gmm_heading.predict(self.conv_heading(features), eps=eps.get('heading'))
+            sem_obj_feature = self.conv_sem_obj(features)
         end_points = decode_scores(pred_center, pred_size, pred_heading, sem_obj_feature, end_points)
         return end_points, (features.transpose(1, 2).contiguous() if export_proposal_feature else None)
 
     def generate(self, xyz, features, end_points, export_proposal_feature=False):
         features = self._aggregate(xyz, features, end_points)
-        kw = dict(return_pi=True, multi_modes=self.multi_mode, n_samples=self.n_samples)
-        pred_center, pi_center = self.gmm_center.generate(self.conv_center(features), **kw)
-        pred_size, pi_size = self.gmm_size.generate(self.conv_size(features), **kw)
-        pred_heading, pi_heading = self.gmm_heading.generate(self.conv_heading(features), **kw)
-        sem_obj_feature = self.conv_sem_obj(features)
+        from .. import pw_op
+        if USE_FUSED_HEADS and not self.multi_mode and pw_op.proposal_heads_supported(self, features):
+            pred_center, pred_size, pred_heading, sem_obj_feature, (pi_center, pi_size, pi_heading) = \
+                pw_op.proposal_heads(self, features, False, return_pi=True)
+        else:
+            kw = dict(return_pi=True, multi_modes=self.multi_mode, n_samples=self.n_samples)
+            pred_center, pi_center = self.gmm_center.generate(self.conv_center(features), **kw)
+            pred_size, pi_size = self.gmm_size.generate(self.conv_size(features), **kw)
+            pred_heading, pi_heading = self.gmm_heading.generate(self.conv_heading(features), **kw)
+            sem_obj_feature = self.conv_sem_obj(features)
         end_points = decode_scores(pred_center, pred_size, pred_heading, sem_obj_feature, end_points)
         end_points['pi'] = {'center': pi_center, 'size': pi_size, 'heading': pi_heading}
         return end_points, (features.transpose(1, 2).contiguous() if export_proposal_feature else None)

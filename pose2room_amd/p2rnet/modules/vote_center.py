@@ -7,6 +7,9 @@ from ..registers import MODULES
 from .sub_modules import SingleConv
 
 
+USE_FUSED_HEAD = True       # tests switch it off to reach the module chain
+
+
 @MODULES.register_module
 class CenterVoteModule(nn.Module):
     def __init__(self, cfg, optim_spec=None):
@@ -26,7 +29,11 @@ class CenterVoteModule(nn.Module):
         """seed_xyz (B,S,J,3), seed_features (B,S,C) -> vote_xyz (B,S*vf,3), vote_features (B,S*vf,C)."""
         hip = seed_xyz[:, :, self.origin_joint_id]
         b, s = hip.shape[0], hip.shape[1]
-        net = self.conv_input(seed_features.transpose(1, 2))
+        from .. import pw_op
+        if USE_FUSED_HEAD and pw_op.vote_head_supported(self, seed_features):
+            net = pw_op.vote_head(self, seed_features)      # csrc/pw_layers.hip: one launch per layer
+        else:
+            net = self.conv_input(seed_features.transpose(1, 2))
         net = net.transpose(2, 1).view(b, s, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (hip.unsqueeze(2) + net[..., 0:3]).contiguous().view(b, s * self.vote_factor, 3)
         vote_features = (seed_features.unsqueeze(2) + net[..., 3:]).contiguous()
