@@ -528,17 +528,38 @@ typedef struct p2r_pw_rjob {
 int p2r_pw_reduce(int njobs, const p2r_pw_rjob *jobs, void *stream);
 
 /* Mixture-density read-out (mdn.py:34-83, MixtureDensityHead.generate_point_predictions with n_samples = 1 and
- * the mixture weights as gates): pred[b, l, d] = sum_g sigmoid(logit[b, g, l]) * (mu[g, d] + exp(log_sigma[g, d]) *
- * eps[(b * L + l), g, d]).  logit (B, G, L) f32 inside a tensor of logit_ctot channels; mu / eps / pred are f32
- * (f64 == 0) or f64 (the heading head, whose `mu` is a float64 parameter); log_sigma f32; eps == NULL: the mixture
- * mean (get_mean, mdn.py:85-99).  pi (B, G, L) f32 optional output.  D <= 4. */
-int p2r_mdn_mix_forward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot, const void *mu,
-                        const float *log_sigma, const void *eps, void *pred, float *pi, void *stream);
-/* its gradient: dpred (B, L, D) -> dlogit (B, G, L) f32 (inside a tensor of dlogit_ctot channels), dmu [G][D]
- * (f32 / f64 like mu), dlog_sigma [G][D] f32; one workgroup per component g. */
-int p2r_mdn_mix_backward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot, const void *mu,
-                         const float *log_sigma, const void *eps, const void *dpred, float *dlogit, int dlogit_ctot,
-                         void *dmu, float *dlog_sigma, void *stream);
+ * the mixture weights as gates), up to four heads per launch:
+ *   pred[b, l, d] = sum_g sigmoid(logit[b, g, l]) * (mu[g, d] + exp(log_sigma[g, d]) * eps[(b * L + l), g, d]).
+ * logit (B, G, L) f32 inside a tensor of logit_ctot channels (pointer pre-offset); mu / eps / pred / dpred / dmu are f32
+ * (f64 == 0) or f64 (the heading head, whose `mu` is a float64 parameter); log_sigma, dlog_sigma f32; eps == NULL:
+ * the mixture mean (get_mean, mdn.py:85-99).  pi (B, G, L) f32 optional output.  D <= 4.
+ * Backward: dpred (B, L, D) -> dlogit (B, G, L) f32 (inside a tensor of dlogit_ctot channels), dmu [G][D],
+ * dlog_sigma [G][D]; one workgroup per (head, component). */
+typedef struct p2r_mix_head {
+  const float *logit, *log_sigma;
+  const void *mu, *eps, *dpred;
+  void *pred, *dmu;
+  float *pi, *dlogit, *dlog_sigma;
+  int D, f64;
+} p2r_mix_head;
+#define P2R_MIX_MAX_HEADS 4
+int p2r_mdn_mix_forward(int nheads, const p2r_mix_head *heads, int B, int G, int L, int logit_ctot, void *stream);
+int p2r_mdn_mix_backward(int nheads, const p2r_mix_head *heads, int B, int G, int L, int logit_ctot, int dlogit_ctot,
+                         void *stream);
+
+/* ---- seams of the ST-GCN backbone (csrc/seed_ops.hip) ------------------------------------------------------------ */
+
+/* frame gather in front of conv_joint (stgcn.py:142-149; conv_joint is pointwise in time, so the gather may come
+ * first): x (b,c,t,j) f32, inds (b,s) int64 -> out (b,s,c*j), out[b,s,ci*j+ji] = x[b,ci,inds[b,s],ji]. */
+int p2r_gather_frames(int b, int c, int t, int j, int s, const float *x, const long long *inds, float *out,
+                      void *stream);
+/* its gradient: dout (b,s,c*j) -> dx (b,c,t,j), every element written (zeros for frames no seed picked; rows of
+ * seeds that share a frame are added in seed order). */
+int p2r_gather_frames_grad(int b, int c, int t, int j, int s, const float *dout, const long long *inds, float *dx,
+                           void *stream);
+/* out[r] = scale * sum_v x[r*v_len + v], v_len <= 64 (mean over the 20-frame window of the position embedding,
+ * stgcn.py:118-121; sum over the 53 joints = the gradient of its broadcast add, stgcn.py:129-130). */
+int p2r_rowsum_short(long long rows, int v_len, float scale, const float *x, float *out, void *stream);
 
 #ifdef __cplusplus
 }

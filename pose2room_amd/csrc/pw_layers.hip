@@ -535,62 +535,75 @@ __global__ __launch_bounds__(256) void pw_reduce_kernel(PwRJobs jobs, int njobs)
   J.out[i] = (a0 + a1) + (a2 + a3);
 }
 
-// ---- mixture read-out -------------------------------------------------------------------------------------------------
+// ---- mixture read-out ------------------------------------------------------------------------------------------------
 constexpr int MIX_DMAX = 4;
+struct MixHeads { p2r_mix_head h[P2R_MIX_MAX_HEADS]; };
 
+// forward: a workgroup owns 16 columns of one head; thread (c = tid & 15, s = tid >> 4) takes components s, s + 16, ...;
+// the 16 slices meet in LDS.  logit reads are 64-byte runs, a column's noise (G * D values) stays in L1 for the block.
 template <typename T>
-__global__ __launch_bounds__(256) void mdn_mix_forward_kernel(int cols, int G, int L, int D, const float *__restrict__ logit,
-                                                              int ctot, const T *__restrict__ mu,
-                                                              const float *__restrict__ log_sigma,
-                                                              const T *__restrict__ eps, T *__restrict__ pred,
-                                                              float *__restrict__ pi) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= cols) return;
-  const int b = col / L, l = col - b * L;
+__device__ __forceinline__ void mix_forward_body(const p2r_mix_head &H, int cols, int G, int L, int ctot, double *red) {
+  const int tid = threadIdx.x, c = tid & 15, s = tid >> 4;
+  const int col = blockIdx.x * 16 + c;
+  const int D = H.D;
+  const T *mu = (const T *)H.mu, *eps = (const T *)H.eps;
   T acc[MIX_DMAX];
 #pragma unroll
   for (int d = 0; d < MIX_DMAX; ++d) acc[d] = (T)0;
-  for (int gi = 0; gi < G; ++gi) {
-    const float lg = logit[((size_t)b * ctot + gi) * L + l];
-    const float p = 1.f / (1.f + expf(-lg));
-    if (pi) pi[((size_t)b * G + gi) * L + l] = p;
+  if (col < cols) {
+    const int b = col / L, l = col - b * L;
+    for (int gi = s; gi < G; gi += 16) {
+      const float lg = H.logit[((size_t)b * ctot + gi) * L + l];
+      const float p = 1.f / (1.f + expf(-lg));
+      if (H.pi) H.pi[((size_t)b * G + gi) * L + l] = p;
 #pragma unroll
-    for (int d = 0; d < MIX_DMAX; ++d) {
-      if (d < D) {
-        T comp = mu[gi * D + d];
-        if (eps) comp = eps[((size_t)col * G + gi) * D + d] * (T)expf(log_sigma[gi * D + d]) + comp;
-        acc[d] += comp * (T)p;
+      for (int d = 0; d < MIX_DMAX; ++d) {
+        if (d < D) {
+          T comp = mu[gi * D + d];
+          if (eps) comp = eps[((size_t)col * G + gi) * D + d] * (T)expf(H.log_sigma[gi * D + d]) + comp;
+          acc[d] += comp * (T)p;
+        }
       }
     }
   }
 #pragma unroll
-  for (int d = 0; d < MIX_DMAX; ++d)
-    if (d < D) pred[(size_t)col * D + d] = acc[d];
+  for (int d = 0; d < MIX_DMAX; ++d) red[(d * 16 + s) * 16 + c] = (double)acc[d];
+  __syncthreads();
+  if (tid < 16 * D) {                      // thread (d, c): slices added in order
+    const int d = tid >> 4, cc = tid & 15;
+    T tot = (T)0;
+    for (int i = 0; i < 16; ++i) tot += (T)red[(d * 16 + i) * 16 + cc];
+    const int ocol = blockIdx.x * 16 + cc;
+    if (ocol < cols) ((T *)H.pred)[(size_t)ocol * D + d] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void mdn_mix_forward_kernel(MixHeads heads, int cols, int G, int L, int ctot) {
+  __shared__ double red[MIX_DMAX * 16 * 16];
+  const p2r_mix_head &H = heads.h[blockIdx.y];
+  if (H.f64) mix_forward_body<double>(H, cols, G, L, ctot, red);
+  else mix_forward_body<float>(H, cols, G, L, ctot, red);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void mdn_mix_backward_kernel(int cols, int G, int L, int D,
-                                                               const float *__restrict__ logit, int ctot,
-                                                               const T *__restrict__ mu,
-                                                               const float *__restrict__ log_sigma,
-                                                               const T *__restrict__ eps, const T *__restrict__ dpred,
-                                                               float *__restrict__ dlogit, int dctot, T *__restrict__ dmu,
-                                                               float *__restrict__ dlog_sigma) {
-  __shared__ double red[2 * MIX_DMAX][4];
+__device__ __forceinline__ void mix_backward_body(const p2r_mix_head &H, int cols, int G, int L, int ctot, int dctot,
+                                                  double (*red)[4]) {
   const int gi = blockIdx.x, tid = threadIdx.x;
+  const int D = H.D;
+  const T *mu = (const T *)H.mu, *eps = (const T *)H.eps, *dpred = (const T *)H.dpred;
   T muv[MIX_DMAX];
   float sig[MIX_DMAX];
 #pragma unroll
   for (int d = 0; d < MIX_DMAX; ++d) {
     muv[d] = d < D ? mu[gi * D + d] : (T)0;
-    sig[d] = d < D ? expf(log_sigma[gi * D + d]) : 0.f;
+    sig[d] = d < D ? expf(H.log_sigma[gi * D + d]) : 0.f;
   }
   T smu[MIX_DMAX], ssg[MIX_DMAX];
 #pragma unroll
   for (int d = 0; d < MIX_DMAX; ++d) { smu[d] = (T)0; ssg[d] = (T)0; }
   for (int col = tid; col < cols; col += 256) {
     const int b = col / L, l = col - b * L;
-    const float lg = logit[((size_t)b * ctot + gi) * L + l];
+    const float lg = H.logit[((size_t)b * ctot + gi) * L + l];
     const float p = 1.f / (1.f + expf(-lg));
     T t = (T)0;
 #pragma unroll
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(256) void mdn_mix_backward_kernel(int cols, int G, 
         ssg[d] += dsamp * e;
       }
     }
-    dlogit[((size_t)b * dctot + gi) * L + l] = (float)t * (p * (1.f - p));
+    H.dlogit[((size_t)b * dctot + gi) * L + l] = (float)t * (p * (1.f - p));
   }
   // block sums (fp64 staging serves both element types)
 #pragma unroll
@@ -618,9 +631,16 @@ __global__ __launch_bounds__(256) void mdn_mix_backward_kernel(int cols, int G, 
   if (tid < D) {
     const double a = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
     const double c = (red[MIX_DMAX + tid][0] + red[MIX_DMAX + tid][1]) + (red[MIX_DMAX + tid][2] + red[MIX_DMAX + tid][3]);
-    dmu[gi * D + tid] = (T)a;
-    dlog_sigma[gi * D + tid] = (float)((T)c) * sig[tid];
+    ((T *)H.dmu)[gi * D + tid] = (T)a;
+    H.dlog_sigma[gi * D + tid] = (float)((T)c) * sig[tid];
   }
+}
+
+__global__ __launch_bounds__(256) void mdn_mix_backward_kernel(MixHeads heads, int cols, int G, int L, int ctot, int dctot) {
+  __shared__ double red[2 * MIX_DMAX][4];
+  const p2r_mix_head &H = heads.h[blockIdx.y];
+  if (H.f64) mix_backward_body<double>(H, cols, G, L, ctot, dctot, red);
+  else mix_backward_body<float>(H, cols, G, L, ctot, dctot, red);
 }
 
 }  // namespace
@@ -732,40 +752,36 @@ extern "C" int p2r_pw_reduce(int njobs, const p2r_pw_rjob *jobs, void *stream) {
   return P2R_OK;
 }
 
-extern "C" int p2r_mdn_mix_forward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot,
-                                   const void *mu, const float *log_sigma, const void *eps, void *pred, float *pi,
+extern "C" int p2r_mdn_mix_forward(int nheads, const p2r_mix_head *heads, int B, int G, int L, int logit_ctot,
                                    void *stream) {
-  if (B < 0 || G <= 0 || L <= 0 || D <= 0 || D > MIX_DMAX || !logit || !mu || !pred || (eps && !log_sigma))
-    return P2R_EINVAL;
+  if (nheads < 1 || nheads > P2R_MIX_MAX_HEADS || !heads || B < 0 || G <= 0 || L <= 0) return P2R_EINVAL;
   if (B == 0) return P2R_OK;
+  MixHeads mh;
+  for (int i = 0; i < nheads; ++i) {
+    const p2r_mix_head &h = heads[i];
+    if (h.D <= 0 || h.D > MIX_DMAX || !h.logit || !h.mu || !h.pred || (h.eps && !h.log_sigma)) return P2R_EINVAL;
+    mh.h[i] = h;
+  }
   const int cols = B * L;
-  if (f64)
-    hipLaunchKernelGGL(mdn_mix_forward_kernel<double>, dim3((unsigned)p2r_cdiv(cols, 256)), dim3(256), 0,
-                       p2r_stream(stream), cols, G, L, D, logit, logit_ctot, (const double *)mu, log_sigma,
-                       (const double *)eps, (double *)pred, pi);
-  else
-    hipLaunchKernelGGL(mdn_mix_forward_kernel<float>, dim3((unsigned)p2r_cdiv(cols, 256)), dim3(256), 0,
-                       p2r_stream(stream), cols, G, L, D, logit, logit_ctot, (const float *)mu, log_sigma,
-                       (const float *)eps, (float *)pred, pi);
+  hipLaunchKernelGGL(mdn_mix_forward_kernel, dim3((unsigned)p2r_cdiv(cols, 16), (unsigned)nheads), dim3(256), 0,
+                     p2r_stream(stream), mh, cols, G, L, logit_ctot);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
 
-extern "C" int p2r_mdn_mix_backward(int B, int G, int L, int D, int f64, const float *logit, int logit_ctot,
-                                    const void *mu, const float *log_sigma, const void *eps, const void *dpred,
-                                    float *dlogit, int dlogit_ctot, void *dmu, float *dlog_sigma, void *stream) {
-  if (B <= 0 || G <= 0 || L <= 0 || D <= 0 || D > MIX_DMAX || !logit || !mu || !log_sigma || !dpred || !dlogit ||
-      !dmu || !dlog_sigma)
-    return P2R_EINVAL;
-  const int cols = B * L;
-  if (f64)
-    hipLaunchKernelGGL(mdn_mix_backward_kernel<double>, dim3((unsigned)G), dim3(256), 0, p2r_stream(stream), cols, G, L,
-                       D, logit, logit_ctot, (const double *)mu, log_sigma, (const double *)eps, (const double *)dpred,
-                       dlogit, dlogit_ctot, (double *)dmu, dlog_sigma);
-  else
-    hipLaunchKernelGGL(mdn_mix_backward_kernel<float>, dim3((unsigned)G), dim3(256), 0, p2r_stream(stream), cols, G, L,
-                       D, logit, logit_ctot, (const float *)mu, log_sigma, (const float *)eps, (const float *)dpred,
-                       dlogit, dlogit_ctot, (float *)dmu, dlog_sigma);
+extern "C" int p2r_mdn_mix_backward(int nheads, const p2r_mix_head *heads, int B, int G, int L, int logit_ctot,
+                                    int dlogit_ctot, void *stream) {
+  if (nheads < 1 || nheads > P2R_MIX_MAX_HEADS || !heads || B <= 0 || G <= 0 || L <= 0) return P2R_EINVAL;
+  MixHeads mh;
+  for (int i = 0; i < nheads; ++i) {
+    const p2r_mix_head &h = heads[i];
+    if (h.D <= 0 || h.D > MIX_DMAX || !h.logit || !h.mu || !h.log_sigma || !h.dpred || !h.dlogit || !h.dmu ||
+        !h.dlog_sigma)
+      return P2R_EINVAL;
+    mh.h[i] = h;
+  }
+  hipLaunchKernelGGL(mdn_mix_backward_kernel, dim3((unsigned)G, (unsigned)nheads), dim3(256), 0, p2r_stream(stream), mh,
+                     B * L, G, L, logit_ctot, dlogit_ctot);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -50,6 +50,11 @@ class _RJob(ctypes.Structure):
     _fields_ = [('in_', _P), ('out', _P), ('P', _I), ('M', _I)]
 
 
+class _MixHead(ctypes.Structure):
+    _fields_ = [(n, _P) for n in ('logit', 'log_sigma', 'mu', 'eps', 'dpred', 'pred', 'dmu', 'pi', 'dlogit',
+                                  'dlog_sigma')] + [('D', _I), ('f64', _I)]
+
+
 def _at(t, off=0):
     """device address of element `off` (in elements) of tensor t; None -> NULL"""
     if t is None:
@@ -131,17 +136,43 @@ def _w2(conv):
     return conv.weight.reshape(conv.out_channels, conv.in_channels).contiguous()
 
 
-def _mix_forward(logits, off, G, L, mdn, eps, train_sample):
-    """logits (B, Ctot, L) f32 holding this head's G rows from channel `off`; -> pred (B, L, D) in mu's dtype."""
+def _mix_forward(logits, offs, G, L, mdns, eps):
+    """logits (B, Ctot, L) f32 holding head i's G rows from channel offs[i]; eps[i] None: the mixture mean.
+    -> [pred_i (B, L, D_i) in mu_i's dtype]; one launch for all heads."""
     B = logits.shape[0]
-    mu = mdn.mu.contiguous()
-    D = mu.shape[1]
-    pred = torch.empty((B, L, D), dtype=mu.dtype, device=logits.device)
-    _lib.check(_lib.lib().p2r_mdn_mix_forward(
-        B, G, L, D, int(mu.dtype == torch.float64), _P(_at(logits, off * L)), logits.shape[1], _lib.ptr(mu),
-        _lib.ptr(mdn.log_sigma.contiguous()), _lib.ptr(eps) if train_sample else None, _lib.ptr(pred), None,
-        _lib.current_stream(logits.device)), "mdn_mix_forward")
-    return pred
+    heads, preds, keep = [], [], []
+    for off, mdn, e in zip(offs, mdns, eps):
+        mu, ls = mdn.mu.contiguous(), mdn.log_sigma.contiguous()
+        D = mu.shape[1]
+        pred = torch.empty((B, L, D), dtype=mu.dtype, device=logits.device)
+        keep += [mu, ls]
+        preds.append(pred)
+        heads.append(dict(logit=_at(logits, off * L), log_sigma=_at(ls), mu=_at(mu), eps=_at(e), pred=_at(pred), D=D,
+                          f64=int(mu.dtype == torch.float64)))
+    arr = (_MixHead * len(heads))(*[_MixHead(**h) for h in heads])
+    _lib.check(_lib.lib().p2r_mdn_mix_forward(len(heads), arr, B, G, L, logits.shape[1],
+                                              _lib.current_stream(logits.device)), "mdn_mix_forward")
+    return preds
+
+
+def _mix_backward(logits, dlogits, offs, G, L, mdns, eps, dpreds):
+    """-> ([dmu_i], [dlog_sigma_i]); dlogits' rows offs[i] .. offs[i] + G written."""
+    B = logits.shape[0]
+    heads, dmus, dlss, keep = [], [], [], []
+    for off, mdn, e, dp in zip(offs, mdns, eps, dpreds):
+        mu, ls = mdn.mu.contiguous(), mdn.log_sigma.contiguous()
+        D = mu.shape[1]
+        dmu, dls = torch.empty_like(mu), torch.empty((G, D), dtype=torch.float32, device=logits.device)
+        keep += [mu, ls]
+        dmus.append(dmu)
+        dlss.append(dls)
+        heads.append(dict(logit=_at(logits, off * L), log_sigma=_at(ls), mu=_at(mu), eps=_at(e), dpred=_at(dp),
+                          dmu=_at(dmu), dlogit=_at(dlogits, off * L), dlog_sigma=_at(dls), D=D,
+                          f64=int(mu.dtype == torch.float64)))
+    arr = (_MixHead * len(heads))(*[_MixHead(**h) for h in heads])
+    _lib.check(_lib.lib().p2r_mdn_mix_backward(len(heads), arr, B, G, L, logits.shape[1], dlogits.shape[1],
+                                               _lib.current_stream(logits.device)), "mdn_mix_backward")
+    return dmus, dlss
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -251,7 +282,7 @@ class _ProposalHeads(Function):
                         bias=_at(gmms[j].mdn.pi.conv.bias), out=_at(logits, j * G * K), k=128, rows=G, x_ctot=384,
                         out_ctot=3 * G) for j in range(3)], B, K, st)
             eps = [e.contiguous() if e is not None else None for e in (eps_c, eps_s, eps_h)]
-            preds = [_mix_forward(logits, j * G, G, K, gmms[j].mdn, eps[j], eps[j] is not None) for j in range(3)]
+            preds = _mix_forward(logits, [j * G for j in range(3)], G, K, [gm.mdn for gm in gmms], eps)
         ctx.net, ctx.train, ctx.dims = net, train, (B, K, G, nsem)
         ctx.eps = eps
         ctx.save_for_backward(feats, Z1, Z2, Z3, fin1, fin2, fin3, logits, *params)
@@ -293,16 +324,8 @@ class _ProposalHeads(Function):
 
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            dmu, dls = [], []
-            for j, gm in enumerate(gmms):
-                mu = gm.mdn.mu.contiguous()
-                D = mu.shape[1]
-                dmu.append(torch.empty_like(mu))
-                dls.append(torch.empty((G, D), **f32))
-                _lib.check(_lib.lib().p2r_mdn_mix_backward(
-                    B, G, K, D, int(mu.dtype == torch.float64), _P(_at(logits, j * G * K)), 3 * G, _lib.ptr(mu),
-                    _lib.ptr(gm.mdn.log_sigma.contiguous()), _lib.ptr(ctx.eps[j]), _lib.ptr(dpred[j]),
-                    _P(_at(dlogits, j * G * K)), 3 * G, _lib.ptr(dmu[j]), _lib.ptr(dls[j]), st), "mdn_mix_backward")
+            dmu, dls = _mix_backward(logits, dlogits, [j * G for j in range(3)], G, K, [gm.mdn for gm in gmms],
+                                     ctx.eps, dpred)
             # ---- level 4: pi convolutions ----
             b3 = bparts(3, 128)
             _gemm([dict(x=_at(dlogits, j * G * K), w=_at(w['pi', j]), w_t=1, out=_at(g3, j * 128 * K), stats=_at(b3[j]),

@@ -178,7 +178,7 @@ def test_mdn_mix(dev, f64, sample):
     eps = torch.randn(B * L, G, 1, D, device=dev, dtype=mu0.dtype)
     pi = torch.sigmoid(logit)
     ref = head.generate_point_predictions(pi, eps=eps) if sample else head.get_mean(pi)       # (B, D, L)
-    pred = pw_op._mix_forward(logits_all, G, G, L, head, eps, sample)                          # (B, L, D)
+    pred, = pw_op._mix_forward(logits_all, [G], G, L, [head], [eps if sample else None])      # (B, L, D)
     assert pred.dtype == mu0.dtype
     assert _rel(pred.transpose(1, 2), ref) < (1e-12 if f64 else 2e-6)
     if not sample:
@@ -186,11 +186,7 @@ def test_mdn_mix(dev, f64, sample):
     dpred = torch.randn(B, L, D, device=dev, dtype=mu0.dtype)
     gl, gmu, gls = torch.autograd.grad(ref, [logit, head.mu, head.log_sigma], dpred.transpose(1, 2))
     dlogit = torch.zeros(B, 2 * G, L, device=dev)
-    dmu, dls = torch.empty_like(head.mu), torch.empty(G, D, device=dev)
-    _lib.check(_lib.lib().p2r_mdn_mix_backward(
-        B, G, L, D, int(f64), pw_op._P(pw_op._at(logits_all, G * L)), 2 * G, _lib.ptr(head.mu.detach().contiguous()),
-        _lib.ptr(head.log_sigma.detach().contiguous()), _lib.ptr(eps), _lib.ptr(dpred), pw_op._P(pw_op._at(dlogit, G * L)),
-        2 * G, _lib.ptr(dmu), _lib.ptr(dls), _lib.current_stream(dev)), "mdn_mix_backward")
+    (dmu,), (dls,) = pw_op._mix_backward(logits_all, dlogit, [G], G, L, [head], [eps], [dpred])
     assert torch.all(dlogit[:, :G] == 0)
     assert _rel(dlogit[:, G:], gl) < 2e-6
     assert _rel(dmu, gmu) < (1e-12 if f64 else 1e-5)
