@@ -117,10 +117,16 @@ class STGCN(nn.Module):
         win = win.clamp_(0, n_frames - 1)                                      # (T,knn)
         offs = hip[:, win] - hip.unsqueeze(2)                                  # (B,T,knn,3)
         pe = self._mlp(self.pos_embed, offs.reshape(n_batch, n_frames * self.knn, 3).transpose(1, 2).contiguous(), self.knn)
-        pe = pe.view(n_batch, -1, n_frames, self.knn).mean(dim=3)             # (B,64,T)
+        from .. import seed_op
+        pe = pe.view(n_batch, -1, n_frames, self.knn)
+        fused = seed_op.short_rows_supported(pe)       # short-row reductions as streaming kernels (csrc/seed_ops.hip)
+        pe = seed_op.mean_last(pe) if fused else pe.mean(dim=3)               # (B,64,T)
         rel = input_joints - input_joints[:, :, self.origin_joint_id:self.origin_joint_id + 1]
         sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2).contiguous(), n_joints)
-        return sk.view(n_batch, -1, n_frames, n_joints) + pe.unsqueeze(-1)
+        sk = sk.view(n_batch, -1, n_frames, n_joints)
+        if fused and seed_op.short_rows_supported(sk):
+            return seed_op.add_broadcast_last(sk, pe)
+        return sk + pe.unsqueeze(-1)
 
     def forward(self, input_joints, end_points=None):
         end_points = {} if end_points is None else end_points
@@ -145,7 +151,11 @@ class STGCN(nn.Module):
             # conv_joint is pointwise in time (kernel 1), so the reference's conv-then-gather
             # (stgcn.py:142-149) equals gather-then-conv: only the seed frames go through the
             # 3392 -> 256 GEMM, and the frame gather doubles as the re-layout to (.., 64*J) rows.
-            rows = x.permute(0, 2, 1, 3)[torch.arange(n_batch, device=x.device)[:, None], seed_inds]   # (B,S,64,J)
+            from .. import seed_op
+            if seed_op.seed_rows_supported(x, seed_inds):               # one streaming launch each way
+                rows = seed_op.seed_rows(x, seed_inds)                  # (B,S,64*J)
+            else:
+                rows = x.permute(0, 2, 1, 3)[torch.arange(n_batch, device=x.device)[:, None], seed_inds]   # (B,S,64,J)
             seed_features = torch.nn.functional.linear(                 # (B,S,256); feature order c*J + j as in
                 rows.reshape(n_batch, self.n_seeds, -1),                # the reference's (B, 64*J, T) layout
                 self.conv_joint.weight.squeeze(-1), self.conv_joint.bias)

@@ -292,3 +292,51 @@ def test_proposal_heads_generate_means_and_pi(dev):
     for a, b in ((pc, rc), (ps, rs), (ph, rh), (sem, rsem), (pis[0], pic), (pis[1], pis_), (pis[2], pih)):
         assert a.shape == b.shape and a.dtype == b.dtype
         assert _rel(a, b) < 2e-5
+
+
+# ---- seams of the backbone (csrc/seed_ops.hip) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,T,J,S,kind", [(2, 64, 128, 53, 64, 'sorted'), (3, 8, 40, 5, 100, 'dup'), (2, 4, 16, 7, 300, 'many'),
+                                            (1, 64, 256, 53, 512, 'random')])
+def test_seed_rows_match_advanced_indexing(dev, B, C, T, J, S, kind):
+    from pose2room_amd.p2rnet import seed_op
+    g = torch.Generator().manual_seed(5)
+    if kind == 'sorted':
+        inds = torch.sort(torch.stack([torch.randperm(T, generator=g)[:S] for _ in range(B)]), dim=1)[0]
+    elif kind == 'many':        # far more seeds than frames: more hits per frame than the kernel's list holds
+        inds = torch.randint(0, 3, (B, S), generator=g)
+    else:
+        inds = torch.randint(0, T, (B, S), generator=g)
+        if kind == 'dup':
+            inds = torch.sort(inds, dim=1)[0]
+    inds = inds.to(dev)
+    x = _rand((B, C, T, J), 1, dev).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    rows = seed_op.seed_rows(x, inds)
+    ref = xr.permute(0, 2, 1, 3)[torch.arange(B, device=dev)[:, None], inds].reshape(B, S, -1)
+    assert torch.equal(rows, ref)
+    gout = _rand((B, S, C * J), 2, dev)
+    rows.backward(gout)
+    ref.backward(gout)
+    assert _rel(x.grad, xr.grad) < 1e-6
+    assert torch.equal(x.grad == 0, xr.grad == 0)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 20), (3, 5, 7, 53), (1, 1, 1, 1), (2, 3, 1000, 64)])
+def test_short_row_reductions(dev, shape):
+    from pose2room_amd.p2rnet import seed_op
+    x = _rand(shape, 1, dev).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    m, mr = seed_op.mean_last(x), xr.mean(-1)
+    assert _rel(m, mr) < 1e-6
+    gm = _rand(shape[:-1], 2, dev)
+    m.backward(gm), mr.backward(gm)
+    assert _rel(x.grad, xr.grad) < 1e-6
+    b = _rand(shape[:-1], 3, dev).requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    a = _rand(shape, 4, dev).requires_grad_(True)
+    ar = a.detach().clone().requires_grad_(True)
+    y, yr = seed_op.add_broadcast_last(a, b), ar + br.unsqueeze(-1)
+    assert torch.equal(y, yr)
+    gy = _rand(shape, 5, dev)
+    y.backward(gy), yr.backward(gy)
+    assert torch.equal(a.grad, ar.grad) and _rel(b.grad, br.grad) < 2e-6
