@@ -21,49 +21,29 @@
 // positive) -> dH = W2^T dZ2 -> dZ1 = dH * (H > 0) -> dG = W1^T dZ1.  dZ2, dZ1 and dG are written once; the weight
 // gradients dW2 = dZ2 H^T, dW1 = dZ1 G^T are one split-K MFMA product each (gemm_nt_kernel), and dG goes back to
 // the points through group_points_grad (LDS row accumulation, deterministic).
-#include "p2r_common.h"
+#include "pw_mma.h"
 
 namespace {
-
-typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 constexpr int SA_C = 256;         // C0 = C1 = C2
 constexpr int SA_S = 16;          // nsample == MFMA n-tile width
 constexpr int SA_BALLS = 4;       // balls per workgroup (= waves)
 constexpr int SA_COLS = SA_BALLS * SA_S;   // 64
-constexpr int SA_RS = SA_COLS + 4;         // LDS row stride (floats)
+constexpr int SA_RS = PW_RS;              // LDS row stride (floats)
 
-// acc[m][n] += W[rows 64*wave + 16m .. +16][K chunk] . act[K chunk][cols 16n .. +16]
+// acc[m][n] = W[rows 64*wave + 16m .. +16][0 .. 256) . act[0 .. 256)[cols 16n .. +16]: the software-pipelined product of
+// pw_mma.h (weights of the next 64 reduction indices are in flight while the current 64 are multiplied; as a plain
+// load-then-multiply loop the L2 latency of every chunk was exposed: forward 0.34 -> see DESIGN.md)
 __device__ __forceinline__ void sa_layer(const float *__restrict__ W, const float *__restrict__ act,
                                          int wave, int g, int r, floatx4v (&acc)[4][4]) {
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = floatx4v{0.f, 0.f, 0.f, 0.f};
-  for (int kc = 0; kc < SA_C; kc += 64) {
-    float a[4][16];   // W[row 64*wave + 16m + r][kc + 16g .. +16)
+  int rowm[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float4 *wp = reinterpret_cast<const float4 *>(W + (size_t)(64 * wave + 16 * m + r) * SA_C + kc + 16 * g);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 u = wp[q];
-        a[m][4 * q + 0] = u.x; a[m][4 * q + 1] = u.y; a[m][4 * q + 2] = u.z; a[m][4 * q + 3] = u.w;
-      }
-    }
-    const float *brow = act + (kc + 16 * g) * SA_RS + r;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      float b[4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) b[n] = brow[s * SA_RS + 16 * n];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[n], acc[m][n], 0, 0, 0);
-    }
-  }
+  for (int m = 0; m < 4; ++m) rowm[m] = 64 * wave + 16 * m + r;
+  pw_product<false>(W, act, SA_C, SA_C, SA_C / 16, 4, rowm, g, r, acc);
 }
 
 template <bool TRAIN>

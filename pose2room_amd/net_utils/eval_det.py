@@ -76,12 +76,18 @@ def eval_det_cls_wo_mesh(pred, gt, ovthresh=0.25, use_07_metric=False, get_iou_f
 
     image_ids, confidence, BB = [], [], []
     for img_id in pred.keys():
-        for box, score in pred[img_id]:
-            image_ids.append(img_id)
-            confidence.append(score)
-            BB.append(box)
-    confidence = np.array(confidence)
-    BB = np.array(BB)
+        entry = pred[img_id]
+        if isinstance(entry, tuple):            # (corners (n,8,3), scores (n,)) arrays of ap_helper.PredMapCls
+            image_ids += [img_id] * len(entry[1])
+            confidence.append(np.asarray(entry[1]))
+            BB.append(np.asarray(entry[0]).reshape(-1, 8, 3))
+        else:
+            for box, score in entry:
+                image_ids.append(img_id)
+                confidence.append(np.asarray([score]))
+                BB.append(np.asarray(box)[None])
+    confidence = np.concatenate(confidence) if confidence else np.array([])
+    BB = np.concatenate(BB) if BB else np.array([])
     order = np.argsort(-confidence)
     BB = BB[order, ...]
     image_ids = [image_ids[x] for x in order]
@@ -125,7 +131,15 @@ def eval_det_multiprocessing_wo_mesh(pred_all, gt_all, ovthresh=0.25, use_07_met
     truth lists for those images, as in the reference (:443-446), so it appears in the result."""
     pred, gt = {}, {}
     for img_id in pred_all.keys():
-        for classname, bbox, score in pred_all[img_id]:
+        entry = pred_all[img_id]
+        if hasattr(entry, 'class_arrays'):      # ap_helper.PredMapCls: the same lists, read as arrays
+            for classname, boxes, scores in entry.class_arrays():
+                if len(scores) == 0:
+                    continue
+                pred.setdefault(classname, {})[img_id] = (boxes, scores)
+                gt.setdefault(classname, {}).setdefault(img_id, [])
+            continue
+        for classname, bbox, score in entry:
             pred.setdefault(classname, {}).setdefault(img_id, [])
             gt.setdefault(classname, {}).setdefault(img_id, [])
             pred[classname][img_id].append((bbox, score))

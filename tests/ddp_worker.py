@@ -65,11 +65,23 @@ def main():
     # the per-step exchange is what DESIGN.md section 7 states: 8,174,532 + 1,600 gradient bytes, 147,380 buffer bytes
     assert log['total_parameter_size_bytes'] == 8176132 and log['broadcast_buffers'] == 1, log
     assert sum(b.numel() * b.element_size() for b in trainer.net.module.buffers()) == 147380
+    # one gradient exchange per step: every parameter took part (nothing unused, no second pass), the f32 payload left
+    # in one bucket (+ the 1.6 KB f64 bucket), and DDP counted exactly the steps that ran
+    assert int(log['iteration']) == i, log['iteration']          # DDP's counter is zero-based: i + 1 steps ran
+    assert int(log['num_buckets_reduced']) <= 2 and int(log['unused_parameter_size']) == 0, log
+    assert int(log['find_unused_parameters']) == 0 and int(log['has_sync_bn']) == 0
+    # LOCAL_RANK -> device: module, DDP's device_ids / output_device and the current device all name this rank's GPU
+    assert torch.cuda.current_device() == local_rank
+    assert all(p.device.index == local_rank for p in trainer.net.module.parameters())
+    assert str(log['device_ids']).strip() == str(local_rank) and int(log['output_device']) == local_rank, log
     if not share:
-        # one rank per GPU: every rank stages its batches through its OWN pinned pool and copies to its own device
+        # one rank per GPU: pinned staging memory (bench.py's H2D leg, the logging fetch of train_step) is allocated by
+        # this process against ITS device, and the copy engine it feeds is this rank's
         probe = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()
-        assert probe.is_pinned() and torch.cuda.current_device() == local_rank
-        assert all(p.device.index == local_rank for p in trainer.net.module.parameters())
+        assert probe.is_pinned()
+        dst = probe.to(device, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+        assert dst.device.index == local_rank
     if rank == 0:
         print(json.dumps({'world': world, 'backend': dist.get_backend(), 'steps': i + 1,
                           'loss_total': losses['total'],

@@ -89,3 +89,57 @@ def test_voc_ap_forms():
     prec = np.array([1.0, 1.0, 0.66, 0.75, 0.6])
     assert eval_det.voc_ap(rec, prec) == pytest.approx(0.1 * 1.0 + 0.1 * 1.0 + 0.3 * 0.75 + 0.4 * 0.6)
     assert eval_det.voc_ap(rec, prec, use_07_metric=True) == pytest.approx((3 * 1.0 + 3 * 0.75 + 4 * 0.6) / 11.)
+
+
+def test_lazy_prediction_lists_equal_the_reference_lists():
+    """ap_helper.PredMapCls (what assembly_pred_map_cls returns per sample) must BE the reference's list -- same length,
+    order (class-major, then proposal index), tuples -- and the array fast path of the AP evaluation must give the very
+    numbers the tuple-by-tuple path gives (ap_helper.py:294-350, eval_det.py:424-473)."""
+    from pose2room_amd.net_utils import ap_helper, eval_det
+    from pose2room_amd.p2rnet.config import DatasetConfig
+    rng = np.random.default_rng(3)
+    B, K, C = 3, 40, 22
+    corners = rng.normal(size=(B, K, 8, 3))
+    probs = rng.uniform(size=(B, K, C)).astype(np.float32)
+    obj = rng.uniform(size=(B, K)).astype(np.float32)
+    mask = (rng.uniform(size=(B, K)) > 0.4).astype(np.uint8)
+    cls = rng.integers(0, C, (B, K))
+    for per_class in (True, False):
+        cfg = {'conf_thresh': 0.05, 'per_class_proposal': per_class, 'dataset_config': DatasetConfig()}
+        parsed = {'pred_corners_3d': corners, 'sem_cls_probs': probs, 'obj_prob': obj, 'pred_sem_cls': cls}
+        lazy = ap_helper.assembly_pred_map_cls({'pred_mask': mask}, parsed, cfg)['batch_pred_map_cls']
+        # the reference's comprehensions, literally
+        want = []
+        for i in range(B):
+            if per_class:
+                cur = []
+                for ii in range(C):
+                    cur += [(ii, corners[i, j], probs[i, j, ii] * obj[i, j]) for j in range(K)
+                            if mask[i, j] == 1 and obj[i, j] > 0.05]
+            else:
+                cur = [(cls[i, j].item(), corners[i, j], obj[i, j]) for j in range(K) if mask[i, j] == 1 and obj[i, j] > 0.05]
+            want.append(cur)
+        for a, b in zip(lazy, want):
+            assert len(a) == len(b)
+            for (c1, b1, s1), (c2, b2, s2) in zip(a, b):
+                assert c1 == c2 and np.array_equal(b1, b2) and s1 == s2
+            assert len(a) == 0 or (a[-1][0] == b[-1][0] and a[len(a) // 2][2] == b[len(b) // 2][2])
+        # AP: array path == tuple path
+        gts = {i: [(int(rng.integers(0, C)), corners[i, j] + 0.01) for j in range(5)] for i in range(B)}
+        r1 = eval_det.eval_det_multiprocessing_wo_mesh({i: lazy[i] for i in range(B)}, gts, 0.25)
+        r2 = eval_det.eval_det_multiprocessing_wo_mesh({i: want[i] for i in range(B)}, gts, 0.25)
+        assert set(r1[2]) == set(r2[2])
+        for k in r2[2]:
+            assert np.array_equal(np.asarray(r1[2][k]), np.asarray(r2[2][k]), equal_nan=True), k
+            assert np.array_equal(np.asarray(r1[0][k]), np.asarray(r2[0][k]), equal_nan=True)
+
+
+def test_assembly_gt_map_cls_from_tensors():
+    import torch
+    from pose2room_amd.net_utils import ap_helper
+    labels = torch.tensor([[3, 5, 0], [1, 0, 0]])
+    corners = np.arange(2 * 3 * 24, dtype=np.float64).reshape(2, 3, 8, 3)
+    mask = np.array([[1, 1, 0], [1, 0, 0]])
+    out = ap_helper.assembly_gt_map_cls({'sem_cls_label': labels, 'gt_corners_3d': corners, 'box_label_mask': mask})
+    assert [[c for c, _ in s] for s in out] == [[3, 5], [1]]
+    assert np.array_equal(out[0][1][1], corners[0, 1]) and all(isinstance(c, int) for s in out for c, _ in s)

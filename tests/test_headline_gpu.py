@@ -5,8 +5,8 @@ arithmetic the small test shapes never reach.  The ST-GCN backbone on the fused 
 forward / dX / dW / dA, temporal conv, BatchNorm passes and epilogue statistics, embedding MLPs) is compared with
 the SAME weights run through plain torch modules (the reference's formulation: conv1x1 to 704 channels + einsum,
 nn.BatchNorm2d, nn.Conv2d) on the same GPU: seed features and every backbone parameter gradient.  A mis-indexed tile
-shows as an O(1) error; the tolerances (1e-3 forward, 2e-2 backward of each tensor's largest entry; measured worst
-6.9e-3, on a graph-conv weight of the fifth block) only absorb
+shows as an O(1) error; the tolerances (1e-3 forward, 1.5e-2 backward of each tensor's largest entry = about twice
+the measured worst, 6.9e-3 on a graph-conv weight of the fifth block) only absorb
 train-mode BatchNorm's amplification of fp32 summation-order noise over six blocks."""
 import contextlib
 import copy
@@ -35,9 +35,11 @@ def _plain_torch(net):
     """Every fused dispatch of the backbone switched off: the host modules run as plain torch chains."""
     import types
     from pose2room_amd.p2rnet import bn_op, tconv_op
+    from pose2room_amd.p2rnet.modules import proposal_net, vote_center
     saved = (bn_op.supported, tconv_op.supported_embed3)
     bn_op.supported = lambda *a, **k: False
     tconv_op.supported_embed3 = lambda *a, **k: False
+    proposal_net.USE_FUSED_HEADS = vote_center.USE_FUSED_HEAD = False     # nn.Conv1d / nn.BatchNorm1d chains
     for b in net.backbone.st_gcn_networks:
         b.gcn.forward = types.MethodType(_chunked_graph_conv, b.gcn)
     for b in net.backbone.st_gcn_networks:
@@ -48,6 +50,7 @@ def _plain_torch(net):
         yield
     finally:
         bn_op.supported, tconv_op.supported_embed3 = saved
+        proposal_net.USE_FUSED_HEADS = vote_center.USE_FUSED_HEAD = True
 
 
 def test_backbone_at_bench_shape_fused_vs_plain(dev):
@@ -88,8 +91,10 @@ def test_backbone_at_bench_shape_fused_vs_plain(dev):
         if s < 1e-8:
             continue
         worst[k] = (g_a[k] - g_b[k]).abs().max().item() / s
-    bad = {k: v for k, v in worst.items() if not v <= 2e-2}
+    bad = {k: v for k, v in worst.items() if not v <= 1.5e-2}
     print('bench-shape backbone: worst relative gradient error', max(worst.values()), max(worst, key=worst.get))
+    for k in sorted(worst, key=worst.get, reverse=True):          # the per-tensor table goes to the log (pytest -s / -rP)
+        print(f'  {worst[k]:.3e}  {k}')
     assert not bad, bad
 
 
@@ -116,3 +121,47 @@ def test_train_step_at_bench_shape(dev):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (k, a, b)
     v = bench.verify_bench_shape(trainer, batch)
     assert v['losses_finite'] and v['seed_inds_equal']
+
+
+def test_forward_and_loss_at_config1_shape(dev):
+    """BASELINE configs[1] at its full size (bs=8, T=512, J=53): P2RNet forward + detection loss on the HIP path
+    (fused backbone, vote / proposal heads on the job-list kernels, fused vote aggregation, fused loss) against the same
+    weights through the plain torch chain (reference formulation of the graph conv, nn.BatchNorm, nn.Conv1d heads, the
+    composed loss), train mode, same mixture noise.  Votes to 1e-3 of range (train-mode BatchNorm amplification over six
+    blocks); the proposal indices are a discrete function of them, so everything behind is compared when they agree
+    (they do at this seed) and the agreement itself is asserted."""
+    from pose2room_amd.p2rnet import P2RConfig, default_config, METHODS
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    B, T = 8, 512
+    cfg = P2RConfig(default_config('train', data={'num_frames': T}), device=dev)
+    torch.manual_seed(7)
+    net = METHODS.get('P2RNet')(cfg).to(dev).train()
+    ref = copy.deepcopy(net)
+    batch = make_batch(B, T, seed=512, device=dev)
+    g = torch.Generator().manual_seed(11)
+    K, G = 128, cfg.config['data']['num_gaussian']
+    eps = {'center': torch.randn(B * K, G, 1, 3, generator=g).to(dev), 'size': torch.randn(B * K, G, 1, 3, generator=g).to(dev),
+           'heading': torch.randn(B * K, G, 1, 2, generator=g, dtype=torch.float64).to(dev)}
+    with torch.no_grad():
+        est_a = net(dict(batch), eps=eps)
+        loss_a = net.loss(est_a, batch)
+        with _plain_torch(ref):
+            est_b = ref(dict(batch), eps=eps)
+            loss_b = ref.detection_loss.composed(est_b, batch, cfg.dataset_config)
+    torch.cuda.synchronize()
+
+    def rel(k):
+        a, b = est_a[k].double(), est_b[k].double()
+        return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+    assert torch.equal(est_a['seed_inds'], est_b['seed_inds'])
+    for k in ('seed_features', 'vote_xyz', 'vote_features'):
+        assert rel(k) <= 1e-3, (k, rel(k))
+    assert torch.equal(est_a['aggregated_vote_inds'], est_b['aggregated_vote_inds']), \
+        'rounding differences of the votes flipped a proposal choice at this seed'
+    worst = {k: rel(k) for k in ('aggregated_vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores')}
+    assert max(worst.values()) <= 2e-3, worst
+    for k in loss_b:
+        a, b = float(loss_a[k]), float(loss_b[k])
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
+    print('configs[1] forward + loss: worst relative output error', worst)
