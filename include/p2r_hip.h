@@ -392,6 +392,12 @@ int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, cons
 int p2r_embed3_forward(int N, int L, const float *x, const float *W, const float *bias,
                        float *out, void *stream);
 
+/* the same forward + the batch statistics of its output: stats [1][64][3] = (count, mean, M2) per output channel in the
+ * entry format of p2r_bn_finalize (width 3), derived from the first and second moments of the three INPUT rows (the
+ * output is an affine map of them), i.e. without a pass over the (N,64,L) output.  scratch: N * ceil(L/1024) * 10 floats. */
+int p2r_embed3_forward_stats(int N, int L, const float *x, const float *W, const float *bias,
+                             float *out, float *scratch, float *stats, void *stream);
+
 /* its weight / bias gradient: partial [N*64][4] = per (sample, channel) row
  * (sum dout*x0, sum dout*x1, sum dout*x2, sum dout); the caller sums over samples. */
 int p2r_embed3_weight_grad(int N, int L, const float *x, const float *dout, float *partial,

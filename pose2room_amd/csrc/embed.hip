@@ -14,11 +14,16 @@ namespace {
 constexpr int EM_THREADS = 256;
 constexpr int EM_C = 64;
 
+// moments (optional) [gridDim.y * gridDim.x][10]: per workgroup (count, mean of the three INPUT coordinates, their six
+// co-moments sum (x_d - mean_d)(x_e - mean_e), d <= e).  The output is an affine map of three inputs, so the batch
+// statistics of all 64 output channels follow from these ten numbers (embed3_stats_kernel): the statistics pass over
+// the (N, 64, L) output -- 21x the bytes -- is not needed.  Sums are taken about the workgroup's first point.
 __global__ __launch_bounds__(EM_THREADS) void embed3_fwd_kernel(int L, const float *__restrict__ x,
                                                                 const float *__restrict__ W,
                                                                 const float *__restrict__ bias,
-                                                                float *__restrict__ out) {
+                                                                float *__restrict__ out, float *__restrict__ moments) {
   __shared__ float ws[EM_C * 4];
+  __shared__ float red[EM_THREADS / 64][10];
   for (int e = threadIdx.x; e < EM_C; e += EM_THREADS) {
     ws[4 * e + 0] = W[3 * e + 0]; ws[4 * e + 1] = W[3 * e + 1]; ws[4 * e + 2] = W[3 * e + 2];
     ws[4 * e + 3] = bias ? bias[e] : 0.f;
@@ -28,7 +33,8 @@ __global__ __launch_bounds__(EM_THREADS) void embed3_fwd_kernel(int L, const flo
   const float *xn = x + (size_t)n * 3 * L;
   float *on = out + (size_t)n * EM_C * L;
   const int l0 = (blockIdx.x * EM_THREADS + threadIdx.x) * 4;
-  if (l0 >= L) return;
+  const bool live = l0 < L;
+  if (!live && !moments) return;
   const bool vec = (L % 4 == 0) && l0 + 3 < L;
   float xv[3][4];
 #pragma unroll
@@ -40,6 +46,39 @@ __global__ __launch_bounds__(EM_THREADS) void embed3_fwd_kernel(int L, const flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) xv[d][i] = l0 + i < L ? xn[(size_t)d * L + l0 + i] : 0.f;
     }
+  }
+  if (moments) {
+    const int lb = blockIdx.x * EM_THREADS * 4;                 // first point of the workgroup: the pivot
+    const float p0 = xn[lb], p1 = xn[(size_t)L + lb], p2 = xn[2 * (size_t)L + lb];
+    float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (l0 + i < L) {
+        const float a = xv[0][i] - p0, b = xv[1][i] - p1, c = xv[2][i] - p2;
+        m[0] += 1.f; m[1] += a; m[2] += b; m[3] += c;
+        m[4] += a * a; m[5] += a * b; m[6] += a * c; m[7] += b * b; m[8] += b * c; m[9] += c * c;
+      }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m[q] += __shfl_xor(m[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q) red[threadIdx.x >> 6][q] = m[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) t[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+      const float cnt = t[0], ia = t[1] / cnt, ib = t[2] / cnt, ic = t[3] / cnt;
+      float *o = moments + ((size_t)n * gridDim.x + blockIdx.x) * 10;
+      o[0] = cnt; o[1] = p0 + ia; o[2] = p1 + ib; o[3] = p2 + ic;
+      o[4] = t[4] - t[1] * ia; o[5] = t[5] - t[1] * ib; o[6] = t[6] - t[1] * ic;
+      o[7] = t[7] - t[2] * ib; o[8] = t[8] - t[2] * ic; o[9] = t[9] - t[3] * ic;
+    }
+    if (!live) return;
   }
 #pragma unroll 8
   for (int c = 0; c < EM_C; ++c) {
@@ -54,6 +93,64 @@ __global__ __launch_bounds__(EM_THREADS) void embed3_fwd_kernel(int L, const flo
       for (int i = 0; i < 4; ++i)
         if (l0 + i < L) on[(size_t)c * L + l0 + i] = o[i];
     }
+  }
+}
+
+// part [P][10] (embed3_fwd_kernel) -> stats [64][3] = (count, mean, M2) of every output channel c of W . x + bias:
+// mean_c = bias_c + W_c . mean_x, M2_c = W_c^T Cov W_c with Cov the co-moment matrix of the inputs about their global
+// mean (workgroup entries merged as M2 = sum [M2_p + n_p (mean_p - mean)(mean_p - mean)^T], in fp64).
+__global__ __launch_bounds__(256) void embed3_stats_kernel(int P, const float *__restrict__ part,
+                                                           const float *__restrict__ W, const float *__restrict__ bias,
+                                                           float *__restrict__ stats) {
+  __shared__ double red[4][10];
+  __shared__ double tot[10];
+  const int tid = threadIdx.x;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int p = tid; p < P; p += 256) {
+    const float *e = part + (size_t)p * 10;
+    const double n = (double)e[0];
+    a[0] += n; a[1] += n * (double)e[1]; a[2] += n * (double)e[2]; a[3] += n * (double)e[3];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][q] = a[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double n = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    tot[0] = n;
+    for (int q = 1; q < 4; ++q) tot[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) / n;
+  }
+  __syncthreads();
+  const double m0 = tot[1], m1 = tot[2], m2 = tot[3];
+  double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int p = tid; p < P; p += 256) {
+    const float *e = part + (size_t)p * 10;
+    const double n = (double)e[0], d0 = (double)e[1] - m0, d1 = (double)e[2] - m1, d2 = (double)e[3] - m2;
+    c[0] += (double)e[4] + n * d0 * d0; c[1] += (double)e[5] + n * d0 * d1; c[2] += (double)e[6] + n * d0 * d2;
+    c[3] += (double)e[7] + n * d1 * d1; c[4] += (double)e[8] + n * d1 * d2; c[5] += (double)e[9] + n * d2 * d2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c[q] += __shfl_xor(c[q], off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][q] = c[q];
+  }
+  __syncthreads();
+  if (tid < 6) tot[4 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+  if (tid < EM_C) {
+    const double w0 = (double)W[3 * tid], w1 = (double)W[3 * tid + 1], w2 = (double)W[3 * tid + 2];
+    const double mean = (bias ? (double)bias[tid] : 0.0) + w0 * m0 + w1 * m1 + w2 * m2;
+    double M2 = w0 * w0 * tot[4] + w1 * w1 * tot[7] + w2 * w2 * tot[9] +
+                2.0 * (w0 * w1 * tot[5] + w0 * w2 * tot[6] + w1 * w2 * tot[8]);
+    if (M2 < 0.0) M2 = 0.0;
+    stats[3 * tid] = (float)tot[0];
+    stats[3 * tid + 1] = (float)mean;
+    stats[3 * tid + 2] = (float)M2;
   }
 }
 
@@ -109,7 +206,23 @@ extern "C" int p2r_embed3_forward(int N, int L, const float *x, const float *W, 
   if (N < 0 || L <= 0 || N > 65535) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   dim3 grid(p2r_cdiv(L, EM_THREADS * 4), N);
-  hipLaunchKernelGGL(embed3_fwd_kernel, grid, dim3(EM_THREADS), 0, p2r_stream(stream), L, x, W, bias, out);
+  hipLaunchKernelGGL(embed3_fwd_kernel, grid, dim3(EM_THREADS), 0, p2r_stream(stream), L, x, W, bias, out,
+                     (float *)nullptr);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// The same forward that also returns the batch statistics of its output for the BatchNorm that follows:
+// stats [1][64][3] = (count, mean, M2) per output channel (the entry format of p2r_bn_finalize, width 3), derived from the
+// moments of the three inputs -- no pass over the output.  scratch: N * ceil(L / 1024) * 10 floats.
+extern "C" int p2r_embed3_forward_stats(int N, int L, const float *x, const float *W, const float *bias, float *out,
+                                        float *scratch, float *stats, void *stream) {
+  if (N <= 0 || L <= 0 || N > 65535 || !scratch || !stats) return P2R_EINVAL;
+  dim3 grid(p2r_cdiv(L, EM_THREADS * 4), N);
+  hipLaunchKernelGGL(embed3_fwd_kernel, grid, dim3(EM_THREADS), 0, p2r_stream(stream), L, x, W, bias, out, scratch);
+  P2R_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed3_stats_kernel, dim3(1), dim3(256), 0, p2r_stream(stream), (int)(grid.x * N), scratch, W, bias,
+                     stats);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

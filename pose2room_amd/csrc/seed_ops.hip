@@ -7,9 +7,9 @@
 // (B, 64, T, J) to (B, S, 64 J) rows.  As ATen ops that is an advanced-indexing gather (255 us at bs=32, T=1024) and,
 // backward, a zero fill + index sort + indexing_backward + permute copy (400 us); here one streaming launch each way:
 // forward one workgroup per (sample, seed) copies 64 runs of J floats into one contiguous row; backward one workgroup
-// per (sample, frame) finds the seeds that picked the frame (wave ballots over the seed list: any order, duplicates
-// allowed), adds their rows in seed order (deterministic) and writes the frame's 64 runs, zeros included -- the whole
-// gradient tensor is written exactly once.
+// per (sample, 8 consecutive frames) finds the seeds that picked each frame (wave ballots over the seed list: any order,
+// duplicates allowed), adds their rows in seed order (deterministic) and writes, per channel, one contiguous run of
+// 8 x J floats, zeros included -- the whole gradient tensor is written exactly once.
 #include "p2r_common.h"
 
 namespace {
@@ -31,43 +31,50 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(int C, int T, int J,
   }
 }
 
-constexpr int GF_MAXHIT = 64;
+constexpr int GF_TT = 8;            // frames per workgroup: runs of GF_TT * J floats (1696 bytes at J = 53) per channel
+constexpr int GF_MAXHIT = 16;       // seeds per frame kept in the list; more (S >> T only) falls back to a scan
 
 __global__ __launch_bounds__(256) void gather_frames_grad_kernel(int C, int T, int J, int S,
                                                                  const float *__restrict__ dout,
                                                                  const long long *__restrict__ inds,
                                                                  float *__restrict__ dx) {
-  __shared__ int hits[GF_MAXHIT];
-  __shared__ int nhit;
-  const int b = blockIdx.x / T, t = blockIdx.x - b * T;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid < 64) {                                 // wave 0: seeds of this sample that picked frame t, ascending
+  __shared__ int hits[GF_TT][GF_MAXHIT];
+  __shared__ int nhit[GF_TT];
+  const int chunks = (T + GF_TT - 1) / GF_TT;
+  const int b = blockIdx.x / chunks, t0 = (blockIdx.x - b * chunks) * GF_TT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave w: the seeds of this sample that picked frames t0 + 2 w and t0 + 2 w + 1, ascending
+  for (int f = 2 * wave; f < 2 * wave + 2; ++f) {
+    const long long t = t0 + f;
     int cnt = 0;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int s0 = 0; s0 < S; s0 += 64) {
       const int s = s0 + lane;
-      const bool hit = s < S && inds[(size_t)b * S + s] == (long long)t;
+      const bool hit = s < S && inds[(size_t)b * S + s] == t;
       const unsigned long long m = __ballot(hit);
       const int slot = cnt + (int)__builtin_popcountll(m & lt);
-      if (hit && slot < GF_MAXHIT) hits[slot] = s;
+      if (hit && slot < GF_MAXHIT) hits[f][slot] = s;
       cnt += (int)__builtin_popcountll(m);
     }
-    if (lane == 0) nhit = cnt;
+    if (lane == 0) nhit[f] = cnt;
   }
   __syncthreads();
-  const int cnt = nhit;
-  const int n = C * J;
-  float *xb = dx + ((size_t)b * C * T + t) * J;
-  for (int e = tid; e < n; e += 256) {
-    float acc = 0.f;
-    if (cnt <= GF_MAXHIT) {
-      for (int i = 0; i < cnt; ++i) acc += dout[((size_t)b * S + hits[i]) * n + e];
-    } else {                                      // more seeds on one frame than the list holds: scan (S >> T only)
-      for (int s = 0; s < S; ++s)
-        if (inds[(size_t)b * S + s] == (long long)t) acc += dout[((size_t)b * S + s) * n + e];
+  const int n = C * J, run = GF_TT * J;
+  for (int e = tid; e < run; e += 256) {          // thread <-> (frame, joint) of the chunk, all channels
+    const int f = e / J, j = e - f * J;
+    if (t0 + f >= T) continue;
+    const int cnt = nhit[f];
+    float *xb = dx + ((size_t)b * C * T + t0) * J + e;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      if (cnt <= GF_MAXHIT) {
+        for (int i = 0; i < cnt; ++i) acc += dout[((size_t)b * S + hits[f][i]) * n + c * J + j];
+      } else {
+        for (int s = 0; s < S; ++s)
+          if (inds[(size_t)b * S + s] == (long long)(t0 + f)) acc += dout[((size_t)b * S + s) * n + c * J + j];
+      }
+      xb[(size_t)c * T * J] = acc;
     }
-    const int c = e / J, j = e - c * J;
-    xb[(size_t)c * T * J + j] = acc;
   }
 }
 
@@ -115,8 +122,8 @@ extern "C" int p2r_gather_frames_grad(int b, int c, int t, int j, int s, const f
                                       float *dx, void *stream) {
   if (b < 0 || c <= 0 || t <= 0 || j <= 0 || s < 0) return P2R_EINVAL;
   if (b == 0) return P2R_OK;
-  hipLaunchKernelGGL(gather_frames_grad_kernel, dim3((unsigned)(b * t)), dim3(256), 0, p2r_stream(stream), c, t, j, s,
-                     dout, inds, dx);
+  hipLaunchKernelGGL(gather_frames_grad_kernel, dim3((unsigned)(b * ((t + GF_TT - 1) / GF_TT))), dim3(256), 0,
+                     p2r_stream(stream), c, t, j, s, dout, inds, dx);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -86,12 +86,17 @@ class STGCN(nn.Module):
                  and not hasattr(s2, 'batchnorm') and tconv_op.supported_embed3(x, s0.conv)
                  and x.shape[2] % inner == 0 and inner <= 64)
         if fused:
-            z = tconv_op.embed3(x, s0.conv).view(x.shape[0], 64, x.shape[2] // inner, inner)
+            z0s = None
+            if s0.batchnorm.training:       # stage-0 statistics from the moments of the three input rows
+                z, z0s = tconv_op.embed3(x, s0.conv, want_stats=True)
+            else:
+                z = tconv_op.embed3(x, s0.conv)
+            z = z.view(x.shape[0], 64, x.shape[2] // inner, inner)
             fused = tconv_op.supported_pointwise(z, s0.batchnorm, s1.conv) and \
                 tconv_op.supported_pointwise(z, s1.batchnorm, s2.conv)
             if fused:
                 if s1.batchnorm.training:   # stage-1 statistics come out of the stage-0 kernel's epilogue
-                    z, zs = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv, want_stats=True)
+                    z, zs = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv, stats=z0s, want_stats=True)
                     z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv, stats=zs)
                 else:
                     z = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv)

@@ -178,21 +178,32 @@ class _Embed3(Function):
     """Conv1d(3 -> 64, kernel 1) on (B,3,L): streaming kernels of csrc/embed.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         x = x.contiguous()
         B, _, L = x.shape
         out = torch.empty((B, 64, L), dtype=torch.float32, device=x.device)
+        w2, b1 = weight.reshape(64, 3).contiguous(), (bias.contiguous() if bias is not None else None)
+        stats = None
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().p2r_embed3_forward(B, L, _lib.ptr(x), _lib.ptr(weight.reshape(64, 3).contiguous()),
-                                                     _lib.ptr(bias.contiguous() if bias is not None else None),
-                                                     _lib.ptr(out), _lib.current_stream(x.device)), "embed3_forward")
+            if want_stats:      # batch statistics of the output from the moments of the three input rows
+                stats = torch.empty((1, 64, 3), dtype=torch.float32, device=x.device)
+                scratch = torch.empty((B * ((L + 1023) // 1024), 10), dtype=torch.float32, device=x.device)
+                _lib.check(_lib.lib().p2r_embed3_forward_stats(B, L, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(b1), _lib.ptr(out),
+                                                               _lib.ptr(scratch), _lib.ptr(stats),
+                                                               _lib.current_stream(x.device)), "embed3_forward_stats")
+            else:
+                _lib.check(_lib.lib().p2r_embed3_forward(B, L, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(b1), _lib.ptr(out),
+                                                         _lib.current_stream(x.device)), "embed3_forward")
         ctx.save_for_backward(x)
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return out, stats
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dstats=None):
         (x,) = ctx.saved_tensors
         assert not ctx.needs_input_grad[0], "embed3: the joint coordinates are inputs, no data gradient"
         dout = dout.contiguous()
@@ -202,7 +213,7 @@ class _Embed3(Function):
             _lib.check(_lib.lib().p2r_embed3_weight_grad(B, L, _lib.ptr(x), _lib.ptr(dout), _lib.ptr(part),
                                                          _lib.current_stream(x.device)), "embed3_weight_grad")
         tot = part.view(B, 64, 4).double().sum(0).float()
-        return None, tot[:, :3].reshape(ctx.wshape).contiguous(), (tot[:, 3].contiguous() if ctx.has_bias else None)
+        return None, tot[:, :3].reshape(ctx.wshape).contiguous(), (tot[:, 3].contiguous() if ctx.has_bias else None), None
 
 
 def supported_embed3(x, conv):
@@ -212,8 +223,9 @@ def supported_embed3(x, conv):
             and conv.groups == 1)
 
 
-def embed3(x, conv):
-    return _Embed3.apply(x, conv.weight, conv.bias)
+def embed3(x, conv, want_stats=False):
+    """want_stats: -> (out, statistics entries [1,64,3] of out for the BatchNorm that follows)"""
+    return _Embed3.apply(x, conv.weight, conv.bias, want_stats)
 
 
 def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False, wp=None):

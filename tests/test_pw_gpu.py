@@ -340,3 +340,20 @@ def test_short_row_reductions(dev, shape):
     gy = _rand(shape, 5, dev)
     y.backward(gy), yr.backward(gy)
     assert torch.equal(a.grad, ar.grad) and _rel(b.grad, br.grad) < 2e-6
+
+
+def test_embed3_statistics_from_input_moments(dev):
+    """p2r_embed3_forward_stats: the (count, mean, M2) entries of the 3 -> 64 layer's output, derived from the moments of
+    its three input rows, against the statistics of the output itself (fp64), incl. inputs far from the origin."""
+    from pose2room_amd.p2rnet import tconv_op, bn_op
+    torch.manual_seed(3)
+    for B, L, off in ((2, 1060, 0.0), (3, 5000, 50.0), (1, 7, 0.0)):
+        x = (torch.randn(B, 3, L, device=dev) * torch.tensor([1.0, 0.3, 2.0], device=dev)[None, :, None] + off).contiguous()
+        conv = torch.nn.Conv1d(3, 64, 1).to(dev)
+        out, stats = tconv_op.embed3(x, conv, want_stats=True)
+        ref = torch.nn.functional.conv1d(x.double(), conv.weight.double(), conv.bias.double())
+        assert _rel(out, ref) < 1e-6
+        assert stats.shape == (1, 64, 3) and float(stats[0, 0, 0]) == B * L
+        mean, var, _ = bn_op.moments(stats, B * L)
+        assert _rel(mean, ref.mean((0, 2))) < 1e-6
+        assert _rel(var, ref.var((0, 2), unbiased=False)) < 1e-5
