@@ -385,6 +385,13 @@ int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, cons
                              const float *Wp, const float *bias, float *out, float *stats_partial,
                              int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream);
 
+/* single-tap p2r_stgcn_tconv3_forward (pointwise 64 -> 64 convolution behind a BatchNorm + ReLU) plus an addend
+ * add_ct (N,64,T) broadcast over the joints: out[n,c,t,w] = bias[c] + add_ct[n,c,t] + sum_ci W[c][ci] relu(x scale + shift)
+ * -- the last layer of the joint embedding and the position embedding's broadcast add (stgcn.py:126-130) in one pass.
+ * Same size / alignment conditions as p2r_stgcn_tconv3_forward. */
+int p2r_stgcn_tconv3_forward_add(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                                 const float *Wp, const float *bias, const float *add_ct, float *out, void *stream);
+
 /* ---- first layer of the embedding MLPs: pointwise Conv1d(3 -> 64) ------------------------ */
 
 /* pos_embed[0] / sk_feat[0] (stgcn.py:46-63): x (N,3,L), W [64][3], bias [64] or NULL ->

@@ -135,10 +135,10 @@ __device__ __forceinline__ void t3_mfma4(f32x4 &acc, const float (&b)[4]) {
 
 // XFORM: input transform relu(x * scale + shift) applied in place to each slice; BWD (data-gradient instance): the
 // statistics epilogue emits the two sums of the BatchNorm + ReLU backward of the layer in front (see stgcn_tconv2.hip).
-template <bool XFORM, bool BWD, int TAPS, int WAVE>
+template <bool XFORM, bool BWD, int TAPS, int WAVE, bool ADDCT = false>
 __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, const float *__restrict__ x,
                                              const float *__restrict__ Wp, float *__restrict__ out, bool want_stats,
-                                             const float *__restrict__ bwd_z) {
+                                             const float *__restrict__ bwd_z, const float *__restrict__ add_ct = nullptr) {
   constexpr int V = T3_V, NW = T3_NW, SLOTS = T3_SLOTS, RS = T3_RS, MAIN = T3_MAIN, HRS = T3_HRS, HALO = T3_HALO,
                 BUF = T3_BUF, NV4 = T3_NV4;
   constexpr int wave = WAVE;
@@ -246,15 +246,31 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
     T3_TRACE_TILE(tile);
     T3_MARK(0);
 
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i)
+    if constexpr (ADDCT) {
+      // accumulators start from bias[c] + add_ct[n, c, t]: a (sample, channel, frame) term broadcast over the joints
+      // (the position embedding added to the joint embedding, stgcn.py:129-130) costs 16 four-byte loads per lane and
+      // tile here instead of a pass over the (N, 64, T, 53) output
+      const float *ab = add_ct + ((size_t)seq * 64 + 4 * g) * p.T + t0 + r;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[i][m][q] = bias_l[16 * m + 4 * g + q];
-    if (QUARTER) {
+        for (int q = 0; q < 4; ++q) {
+          const float v = bias_l[16 * m + 4 * g + q] + ab[(size_t)(16 * m + q) * p.T];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) accq[q] = bias_l[16 * MQ + 4 * g + q];
+          for (int i = 0; i < SLOTS; ++i) acc[i][m][q] = v;
+          if (QUARTER && m == MQ) accq[q] = v;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i][m][q] = bias_l[16 * m + 4 * g + q];
+      if (QUARTER) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accq[q] = bias_l[16 * MQ + 4 * g + q];
+      }
     }
 
 #pragma unroll 1
@@ -487,11 +503,12 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   }
 }
 
-template <bool XFORM, bool BWD, int TAPS>
+template <bool XFORM, bool BWD, int TAPS, bool ADDCT = false>
 __global__ __launch_bounds__(T3_NW * 64, 2) __attribute__((amdgpu_num_vgpr(224))) void tconv3_kernel(
     T3Params p, const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
-    float *__restrict__ stats_partial, const float *__restrict__ bwd_z, const float *__restrict__ bwd_fin) {
+    float *__restrict__ stats_partial, const float *__restrict__ bwd_z, const float *__restrict__ bwd_fin,
+    const float *__restrict__ add_ct) {
   constexpr int NW = T3_NW;
   extern __shared__ float lds[];
   float *rowstat = lds + 2 * T3_BUF;
@@ -510,14 +527,14 @@ __global__ __launch_bounds__(T3_NW * 64, 2) __attribute__((amdgpu_num_vgpr(224))
   __syncthreads();
   const bool want_stats = stats_partial != nullptr;
   switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-    case 0: t3_wave_main<XFORM, BWD, TAPS, 0>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 1: t3_wave_main<XFORM, BWD, TAPS, 1>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 2: t3_wave_main<XFORM, BWD, TAPS, 2>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 3: t3_wave_main<XFORM, BWD, TAPS, 3>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 4: t3_wave_main<XFORM, BWD, TAPS, 4>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 5: t3_wave_main<XFORM, BWD, TAPS, 5>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    case 6: t3_wave_main<XFORM, BWD, TAPS, 6>(p, lds, x, Wp, out, want_stats, bwd_z); break;
-    default: t3_wave_main<XFORM, BWD, TAPS, 7>(p, lds, x, Wp, out, want_stats, bwd_z); break;
+    case 0: t3_wave_main<XFORM, BWD, TAPS, 0, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 1: t3_wave_main<XFORM, BWD, TAPS, 1, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 2: t3_wave_main<XFORM, BWD, TAPS, 2, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 3: t3_wave_main<XFORM, BWD, TAPS, 3, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 4: t3_wave_main<XFORM, BWD, TAPS, 4, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 5: t3_wave_main<XFORM, BWD, TAPS, 5, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    case 6: t3_wave_main<XFORM, BWD, TAPS, 6, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
+    default: t3_wave_main<XFORM, BWD, TAPS, 7, ADDCT>(p, lds, x, Wp, out, want_stats, bwd_z, add_ct); break;
   }
   if (stats_partial) {
     __syncthreads();
@@ -554,16 +571,16 @@ __global__ __launch_bounds__(T3_NW * 64, 2) __attribute__((amdgpu_num_vgpr(224))
   }
 }
 
-template <bool XFORM, bool BWD, int TAPS>
+template <bool XFORM, bool BWD, int TAPS, bool ADDCT = false>
 int tconv3_launch(const T3Params &p, int blocks, size_t lds, const float *x, const float *scale, const float *shift,
                   const float *Wp, const float *bias, float *out, float *stats_partial, const float *bwd_z,
-                  const float *bwd_fin, void *stream) {
-  auto kern = tconv3_kernel<XFORM, BWD, TAPS>;
+                  const float *bwd_fin, void *stream, const float *add_ct = nullptr) {
+  auto kern = tconv3_kernel<XFORM, BWD, TAPS, ADDCT>;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(kern, lds_ok);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(T3_NW * 64), lds, p2r_stream(stream), p, x, scale, shift, Wp, bias, out,
-                     stats_partial, bwd_z, bwd_fin);
+                     stats_partial, bwd_z, bwd_fin, add_ct);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -572,9 +589,10 @@ int tconv3_launch(const T3Params &p, int blocks, size_t lds, const float *x, con
 
 // Arguments and semantics of p2r_stgcn_tconv2_forward; additionally T % 16 == 0 and x, out (and bwd_z) 16-byte aligned
 // (P2R_EINVAL otherwise: the caller uses p2r_stgcn_tconv2_forward).
-extern "C" int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
-                                        const float *Wp, const float *bias, float *out, float *stats_partial,
-                                        int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream) {
+static int tconv3_forward_impl(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
+                               const float *Wp, const float *bias, float *out, float *stats_partial,
+                               int *n_partials, const float *bwd_z, const float *bwd_fin, const float *add_ct,
+                               void *stream) {
   if (N < 0 || T <= 0 || V != T3_V || (taps != 1 && taps != 3) || (scale == nullptr) != (shift == nullptr)) return P2R_EINVAL;
   if ((bwd_z == nullptr) != (bwd_fin == nullptr) || (bwd_z && (scale || !stats_partial))) return P2R_EINVAL;
   if (T % T3_F != 0 || T > (1 << 20) || ((uintptr_t)x % 16) != 0 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)bwd_z % 16) != 0)
@@ -594,8 +612,30 @@ extern "C" int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const flo
                      (size_t)(128 + 64 + 128) * sizeof(float);
 #define P2R_T3(XF, BW) (taps == 3 ? tconv3_launch<XF, BW, 3>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream) \
                                    : tconv3_launch<XF, BW, 1>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin, stream))
+  if (add_ct) {       // single-tap forward through a BatchNorm + ReLU with a (sample, channel, frame) addend
+    if (taps != 1 || !scale || bwd_z) return P2R_EINVAL;
+    return tconv3_launch<true, false, 1, true>(p, blocks, lds, x, scale, shift, Wp, bias, out, stats_partial, bwd_z, bwd_fin,
+                                               stream, add_ct);
+  }
   if (bwd_z) return P2R_T3(false, true);
   if (scale) return P2R_T3(true, false);
   return P2R_T3(false, false);
 #undef P2R_T3
+}
+
+extern "C" int p2r_stgcn_tconv3_forward(int N, int T, int V, int taps, const float *x, const float *scale, const float *shift,
+                                        const float *Wp, const float *bias, float *out, float *stats_partial,
+                                        int *n_partials, const float *bwd_z, const float *bwd_fin, void *stream) {
+  return tconv3_forward_impl(N, T, V, taps, x, scale, shift, Wp, bias, out, stats_partial, n_partials, bwd_z, bwd_fin, nullptr,
+                             stream);
+}
+
+// The single-tap forward (pointwise 64 -> 64 convolution behind a BatchNorm + ReLU) with an addend add_ct (N,64,T) that
+// is broadcast over the joints: out[n,c,t,w] = bias[c] + add_ct[n,c,t] + sum_ci W[c][ci] relu(x[n,ci,t,w] scale + shift)
+// -- the last layer of the joint embedding plus the position embedding (stgcn.py:126-130) in one pass.
+extern "C" int p2r_stgcn_tconv3_forward_add(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                                            const float *Wp, const float *bias, const float *add_ct, float *out,
+                                            void *stream) {
+  if (!add_ct) return P2R_EINVAL;
+  return tconv3_forward_impl(N, T, V, 1, x, scale, shift, Wp, bias, out, nullptr, nullptr, nullptr, nullptr, add_ct, stream);
 }

@@ -75,8 +75,9 @@ class STGCN(nn.Module):
         raise NotImplementedError
 
     @staticmethod
-    def _mlp(seq, x, inner):
+    def _mlp(seq, x, inner, add_ct=None):
         """Run a `_point_mlp` stack (conv-BN-ReLU, conv-BN-ReLU, conv) on x (B,3,L), L = rows * inner.
+        add_ct (B,64,rows): added to the result, broadcast over `inner` (folded into the last layer's kernel).
         On the GPU: the 3->64 layer is a streaming kernel, and each BatchNorm+ReLU is folded into the
         following pointwise 64->64 convolution (one pass per layer instead of GEMM + normalise +
         activate); elsewhere the plain module chain runs."""
@@ -97,10 +98,10 @@ class STGCN(nn.Module):
             if fused:
                 if s1.batchnorm.training:   # stage-1 statistics come out of the stage-0 kernel's epilogue
                     z, zs = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv, stats=z0s, want_stats=True)
-                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv, stats=zs)
+                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv, stats=zs, add_ct=add_ct)
                 else:
                     z = tconv_op.bn_relu_tconv(z, s0.batchnorm, s1.conv)
-                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv)
+                    z = tconv_op.bn_relu_tconv(z, s1.batchnorm, s2.conv, add_ct=add_ct)
                 return z.view(x.shape[0], 64, x.shape[2])
         for stage in seq:
             if x.is_cuda and hasattr(stage, 'batchnorm') and hasattr(stage, 'ReLU') and \
@@ -108,6 +109,8 @@ class STGCN(nn.Module):
                 x = bn_op.fused_bn_act(stage.conv(x), stage.batchnorm, None, relu=True)
             else:
                 x = stage(x)
+        if add_ct is not None:
+            x = (x.view(x.shape[0], x.shape[1], -1, inner) + add_ct.unsqueeze(-1)).view(x.shape)
         return x
 
     def embed(self, input_joints):
@@ -127,11 +130,10 @@ class STGCN(nn.Module):
         fused = seed_op.short_rows_supported(pe)       # short-row reductions as streaming kernels (csrc/seed_ops.hip)
         pe = seed_op.mean_last(pe) if fused else pe.mean(dim=3)               # (B,64,T)
         rel = input_joints - input_joints[:, :, self.origin_joint_id:self.origin_joint_id + 1]
-        sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2).contiguous(), n_joints)
-        sk = sk.view(n_batch, -1, n_frames, n_joints)
-        if fused and seed_op.short_rows_supported(sk):
-            return seed_op.add_broadcast_last(sk, pe)
-        return sk + pe.unsqueeze(-1)
+        # the position embedding is added (broadcast over the joints) inside the last layer of the joint embedding
+        sk = self._mlp(self.sk_feat, rel.reshape(n_batch, n_frames * n_joints, 3).transpose(1, 2).contiguous(), n_joints,
+                       add_ct=pe)
+        return sk.view(n_batch, -1, n_frames, n_joints)
 
     def forward(self, input_joints, end_points=None):
         end_points = {} if end_points is None else end_points

@@ -78,12 +78,29 @@ class _BNReLUTConv(Function):
     constants)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, fin, weight, bias, train, want_stats=False, wp_f=None, wp_b=None):
+    def forward(ctx, z, gamma, beta, fin, weight, bias, train, want_stats=False, wp_f=None, wp_b=None, add_ct=None):
         """wp_f / wp_b: the taps in kernel order for the forward and the data-gradient launch (gcn_op.prepare_chain);
-        only for the (3,1) conv over 53 joints."""
+        only for the (3,1) conv over 53 joints.  add_ct (N,64,T): addend broadcast over the joints (single tap only)."""
         z = z.contiguous()
         taps = weight.numel() // (64 * 64)
-        if wp_f is not None:
+        ctx.has_add = add_ct is not None
+        if add_ct is not None:
+            assert taps == 1 and not want_stats and wp_f is None
+            W3 = weight.reshape(64, 64, 1).permute(2, 0, 1).contiguous()
+            N, C, T, V = z.shape
+            add_c = add_ct.contiguous()
+            if (USE_GEN3 and V == 53 and T % 16 == 0 and z.data_ptr() % 16 == 0 and add_c.shape == (N, C, T)
+                    and add_c.dtype == torch.float32):
+                out = torch.empty_like(z)
+                with torch.cuda.device(z.device):
+                    _lib.check(_lib.lib().p2r_stgcn_tconv3_forward_add(
+                        N, T, V, _lib.ptr(z), _lib.ptr(fin[2]), _lib.ptr(fin[3]), _lib.ptr(_permute_taps(W3)),
+                        _lib.ptr(bias.contiguous() if bias is not None else None), _lib.ptr(add_c), _lib.ptr(out),
+                        _lib.current_stream(z.device)), "stgcn_tconv3_forward_add")
+            else:
+                out = _tconv(z, fin[2], fin[3], W3, bias.contiguous() if bias is not None else None) + add_c.unsqueeze(-1)
+            ctx.save_for_backward(z, fin, W3)
+        elif wp_f is not None:
             assert taps == 3 and z.shape[3] == 53 and wp_b is not None
             W3 = None
             out = _tconv(z, fin[2], fin[3], None, bias.contiguous() if bias is not None else None, want_stats, Wp=wp_f)
@@ -156,7 +173,11 @@ class _BNReLUTConv(Function):
             dW = _lib.sum_leading(part).view(ctx.wshape)      # the kernel writes its partials in the weight's own (c, ci, tap) order
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
                 dbias = _lib.sum_leading(bpart)
-        return dz, dgamma, dbeta, None, dW, dbias, None, None, None, None
+        dadd = None
+        if ctx.has_add and ctx.needs_input_grad[10]:       # the addend was broadcast over the joints: row sums of du
+            from . import seed_op
+            dadd = seed_op._rowsum(du, V, 1.0)
+        return dz, dgamma, dbeta, None, dW, dbias, None, None, None, None, dadd
 
 
 def supported(z, bn, conv):
@@ -228,16 +249,17 @@ def embed3(x, conv, want_stats=False):
     return _Embed3.apply(x, conv.weight, conv.bias, want_stats)
 
 
-def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False, wp=None):
+def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False, wp=None, add_ct=None):
     """stats: kernel partials [P,64,2] of z from its producer (bn_op.moments) instead of a statistics pass;
     want_stats: return (u, partials of u) for the BatchNorm that consumes u;
-    wp: (forward, data-gradient) taps in kernel order from gcn_op.prepare_chain (train mode)."""
+    wp: (forward, data-gradient) taps in kernel order from gcn_op.prepare_chain (train mode);
+    add_ct (N,64,T): added to the result, broadcast over the joints (single-tap convolutions only)."""
     if bn.training:
         part = bn_op._stats_partial(z.contiguous()) if stats is None else stats
         fin = bn_op.finalize(part, z.numel() // z.shape[1], bn)     # also updates the running statistics
         wp_f, wp_b = wp if wp is not None else (None, None)
-        return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats, wp_f, wp_b)
+        return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats, wp_f, wp_b, add_ct)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale]).detach()
-    return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, False, want_stats)
+    return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, False, want_stats, None, None, add_ct)

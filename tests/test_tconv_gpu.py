@@ -109,6 +109,45 @@ def test_bn_relu_pointwise(dev, N, T, V, train):
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
 
+@pytest.mark.parametrize("N,T,V", [(2, 48, 53), (3, 160, 53), (2, 40, 53), (2, 17, 20)])
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_relu_pointwise_with_broadcast_addend(dev, N, T, V, train):
+    """The last layer of the joint embedding with the position embedding folded in (stgcn.py:126-130):
+    conv(relu(bn(z))) + pe[..., None] in one kernel when the statically scheduled path applies (53 joints, T % 16 == 0),
+    composed otherwise; gradients of everything incl. the addend (row sums over the joints)."""
+    from pose2room_amd.p2rnet import tconv_op
+    torch.manual_seed(N * 7 + T)
+    bn_ref = torch.nn.BatchNorm1d(64).to(dev)
+    conv_ref = torch.nn.Conv1d(64, 64, 1).to(dev)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.5, 0.5)
+        bn_ref.running_mean.uniform_(-0.2, 0.2); bn_ref.running_var.uniform_(0.5, 2.0)
+    bn_new, conv_new = copy.deepcopy(bn_ref), copy.deepcopy(conv_ref)
+    bn_ref, conv_ref = bn_ref.double(), conv_ref.double()
+    bn_ref.train(train); bn_new.train(train)
+    z = torch.randn(N, 64, T * V, device=dev) * 1.5 + 0.3
+    pe = torch.randn(N, 64, T, device=dev)
+    go = torch.randn(N, 64, T, V, device=dev)
+    zr, per = z.double().clone().requires_grad_(True), pe.double().clone().requires_grad_(True)
+    ur = conv_ref(torch.relu(bn_ref(zr))).view(N, 64, T, V) + per.unsqueeze(-1)
+    ur.backward(go.double())
+    zn, pen = z.clone().requires_grad_(True), pe.clone().requires_grad_(True)
+    un = tconv_op.bn_relu_tconv(zn.view(N, 64, T, V), bn_new, conv_new, add_ct=pen)
+    un.backward(go)
+
+    def close(a, b, what, tol=3e-5):
+        scale = b.abs().max().item() + 1e-12
+        err = (a.double() - b.double()).abs().max().item()
+        assert err <= tol * scale, f"{what}: {err:.3e} vs {scale:.3e}"
+
+    close(un, ur, "u")
+    close(zn.grad, zr.grad, "dz", 1e-4)
+    close(pen.grad, per.grad, "dpe", 1e-5)
+    close(conv_new.weight.grad, conv_ref.weight.grad, "dW", 1e-4)
+    close(conv_new.bias.grad, conv_ref.bias.grad, "dbias", 1e-4)
+    close(bn_new.weight.grad, bn_ref.weight.grad, "dgamma", 1e-4)
+
+
 @pytest.mark.parametrize("B,L", [(2, 53 * 40), (1, 7), (3, 20 * 33 + 1), (2, 4096)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_embed3(dev, B, L, bias):
