@@ -574,6 +574,16 @@ int p2r_gather_frames_grad(int b, int c, int t, int j, int s, const float *dout,
  * stgcn.py:118-121; sum over the 53 joints = the gradient of its broadcast add, stgcn.py:129-130). */
 int p2r_rowsum_short(long long rows, int v_len, float scale, const float *x, float *out, void *stream);
 
+/* tail of the vote head (vote_center.py:50-58 + the feature normalisation of network.py:68-71) in one launch:
+ * net (b,s,3+256) = conv_input's output per seed, seed_features (b,s,256), hip (b,s,3) -> vote_xyz (b,s,3) = hip + net[:3],
+ * feat_ncl (b,256,s) = (seed_features + net[3:]) / |.|_2 channel-major (what the vote aggregation reads; the reference's
+ * (b,s,256) tensor is its transposed view), inv_norm (b,s).  s % 64 == 0. */
+int p2r_vote_finish(int b, int s, int C, const float *net, const float *seed_features, const float *hip,
+                    float *vote_xyz, float *feat_ncl, float *inv_norm, void *stream);
+/* gradient: d_xyz (b,s,3) / d_feat (b,256,s) (either may be NULL = zero) -> d_net (b,s,3+256), d_sf (b,s,256). */
+int p2r_vote_finish_grad(int b, int s, int C, const float *d_xyz, const float *d_feat, const float *feat_ncl,
+                         const float *inv_norm, float *d_net, float *d_sf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,85 @@ __global__ __launch_bounds__(256) void rowsum_short_kernel(long long rows, int V
   }
 }
 
+// ---- tail of the vote head (vote_center.py:50-58, network.py:68-71) ----------------------------------------------------
+// net (B,S,3+C) = conv_input's output per seed: xyz offset + feature residual.  vote_xyz = hip + net[..., :3];
+// f = seed_features + net[..., 3:]; vote_features = f / |f|_2 (no epsilon, as the reference) -- written channel-major
+// (B,C,S), the layout the vote aggregation reads, so the (B,S,C) tensor the reference holds is its transposed view.
+// One workgroup per 64 seeds: a wave reads whole (B,S,.) rows (one seed = 64 lanes x 4 channels 64 apart), reduces the norm
+// with lane shuffles, and the normalised tile is transposed through LDS.  C = 256.
+constexpr int VF_C = 256, VF_COLS = 64, VF_RS = VF_COLS + 1;
+
+__global__ __launch_bounds__(256) void vote_finish_kernel(int S, const float *__restrict__ net,
+                                                          const float *__restrict__ seed_features,
+                                                          const float *__restrict__ hip, float *__restrict__ vote_xyz,
+                                                          float *__restrict__ feat_ncl, float *__restrict__ inv_norm) {
+  extern __shared__ float tile[];                       // [256][VF_RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t col0 = (size_t)blockIdx.x * VF_COLS;      // S % 64 == 0: the tile lies inside one sample
+  const int b = (int)(col0 / S), s0 = (int)(col0 - (size_t)b * S);
+  for (int i = 0; i < 16; ++i) {
+    const int cl = 16 * wave + i;
+    const size_t col = col0 + cl;
+    const float *nr = net + col * (3 + VF_C);
+    const float *sr = seed_features + col * VF_C;
+    float f[4];                                           // channels lane, lane + 64, lane + 128, lane + 192
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = sr[lane + 64 * e] + nr[3 + lane + 64 * e];
+    float ss = (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = 1.f / sqrtf(ss);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(lane + 64 * e) * VF_RS + cl] = f[e] * inv;
+    if (lane < 3) vote_xyz[col * 3 + lane] = hip[col * 3 + lane] + nr[lane];
+    if (lane == 3) inv_norm[col] = inv;
+  }
+  __syncthreads();
+  float *ob = feat_ncl + (size_t)b * VF_C * S + s0;
+  for (int c = wave; c < VF_C; c += 4) ob[(size_t)c * S + lane] = tile[c * VF_RS + lane];
+}
+
+// gradient: d_xyz (B,S,3), d_feat (B,C,S) w.r.t. the normalised features, feat (B,C,S), inv_norm (B,S) ->
+// d_net (B,S,3+C) = (d_xyz, df), d_sf (B,S,C) = df, df = inv (dy - y (y . dy)).
+__global__ __launch_bounds__(256) void vote_finish_grad_kernel(int S, const float *__restrict__ d_xyz,
+                                                               const float *__restrict__ d_feat,
+                                                               const float *__restrict__ feat,
+                                                               const float *__restrict__ inv_norm,
+                                                               float *__restrict__ d_net, float *__restrict__ d_sf) {
+  extern __shared__ float tile[];                       // dy [256][VF_RS], y [256][VF_RS]
+  float *dy = tile, *y = tile + VF_C * VF_RS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t col0 = (size_t)blockIdx.x * VF_COLS;
+  const int b = (int)(col0 / S), s0 = (int)(col0 - (size_t)b * S);
+  const float *gb = d_feat + (size_t)b * VF_C * S + s0, *yb = feat + (size_t)b * VF_C * S + s0;
+  for (int c = wave; c < VF_C; c += 4) {
+    dy[c * VF_RS + lane] = d_feat ? gb[(size_t)c * S + lane] : 0.f;
+    y[c * VF_RS + lane] = yb[(size_t)c * S + lane];
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    const int cl = 16 * wave + i;
+    const size_t col = col0 + cl;
+    float g[4], v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[e] = dy[(lane + 64 * e) * VF_RS + cl]; v[e] = y[(lane + 64 * e) * VF_RS + cl]; }
+    float dot = (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    const float inv = inv_norm[col];
+    float df[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) df[e] = inv * (g[e] - v[e] * dot);
+    float *nr = d_net + col * (3 + VF_C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      nr[3 + lane + 64 * e] = df[e];
+      d_sf[col * VF_C + lane + 64 * e] = df[e];
+    }
+    if (lane < 3) nr[lane] = d_xyz ? d_xyz[col * 3 + lane] : 0.f;
+  }
+}
+
 }  // namespace
 
 // x (b, c, t, j) f32, inds (b, s) int64 frame indices -> out (b, s, c * j): out[b, s, ci * j + ji] = x[b, ci, inds[b, s], ji]
@@ -135,6 +214,39 @@ extern "C" int p2r_rowsum_short(long long rows, int v_len, float scale, const fl
   const size_t lds = 256 * (size_t)(v_len | 1) * sizeof(float);
   hipLaunchKernelGGL(rowsum_short_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds, p2r_stream(stream), rows,
                      v_len, scale, x, out);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// Tail of the vote head, see vote_finish_kernel.  net (b,s,3+256), seed_features (b,s,256), hip (b,s,3) ->
+// vote_xyz (b,s,3), feat_ncl (b,256,s) = normalised vote features channel-major, inv_norm (b,s) (saved for the gradient).
+// s % 64 == 0, C = 256.
+extern "C" int p2r_vote_finish(int b, int s, int C, const float *net, const float *seed_features, const float *hip,
+                               float *vote_xyz, float *feat_ncl, float *inv_norm, void *stream) {
+  if (b < 0 || s <= 0 || s % VF_COLS != 0 || C != VF_C) return P2R_EINVAL;
+  if (b == 0) return P2R_OK;
+  const size_t lds = (size_t)VF_C * VF_RS * sizeof(float);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(vote_finish_kernel, lds_ok, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(vote_finish_kernel, dim3((unsigned)((size_t)b * s / VF_COLS)), dim3(256), lds, p2r_stream(stream), s, net,
+                     seed_features, hip, vote_xyz, feat_ncl, inv_norm);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// its gradient: d_xyz (b,s,3) or NULL, d_feat (b,256,s) or NULL, feat_ncl / inv_norm from the forward ->
+// d_net (b,s,3+256), d_sf (b,s,256).
+extern "C" int p2r_vote_finish_grad(int b, int s, int C, const float *d_xyz, const float *d_feat, const float *feat_ncl,
+                                    const float *inv_norm, float *d_net, float *d_sf, void *stream) {
+  if (b < 0 || s <= 0 || s % VF_COLS != 0 || C != VF_C) return P2R_EINVAL;
+  if (b == 0) return P2R_OK;
+  const size_t lds = (size_t)2 * VF_C * VF_RS * sizeof(float);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(vote_finish_grad_kernel, lds_ok, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(vote_finish_grad_kernel, dim3((unsigned)((size_t)b * s / VF_COLS)), dim3(256), lds, p2r_stream(stream),
+                     s, d_xyz, d_feat, feat_ncl, inv_norm, d_net, d_sf);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

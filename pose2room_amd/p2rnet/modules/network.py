@@ -81,8 +81,16 @@ class P2RNet(BaseNetwork):
 
     def _votes(self, data):
         end_points = self.backbone(data['input_joints'], {})
-        xyz, features = self.centervoting(end_points['seed_skeleton'], end_points['seed_features'])
-        features = features.div(torch.norm(features, p=2, dim=2).unsqueeze(2))   # no epsilon, as the reference
+        from .. import pw_op
+        from . import vote_center
+        if vote_center.USE_FUSED_HEAD and pw_op.votes_normalized_supported(self.centervoting, end_points['seed_skeleton'],
+                                                                            end_points['seed_features']):
+            # conv_input on the job-list kernels + offset / residual add / normalisation / re-layout in one launch
+            xyz, features = pw_op.votes_normalized(self.centervoting, end_points['seed_skeleton'],
+                                                   end_points['seed_features'])
+        else:
+            xyz, features = self.centervoting(end_points['seed_skeleton'], end_points['seed_features'])
+            features = features.div(torch.norm(features, p=2, dim=2).unsqueeze(2))   # no epsilon, as the reference
         end_points['vote_xyz'] = xyz
         end_points['vote_features'] = features
         return xyz, features, end_points

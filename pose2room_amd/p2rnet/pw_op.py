@@ -533,3 +533,53 @@ def vote_head(module, seed_features):
                           seq[1].conv.weight, seq[1].batchnorm.weight, seq[1].batchnorm.bias, seq[2].conv.weight,
                           seq[2].conv.bias)
     return net.transpose(1, 2)
+
+
+class _VoteFinish(Function):
+    """net (B,S,3+256) memory order, seed_features (B,S,256), hip (B,S,3) -> vote_xyz (B,S,3), vote features
+    normalised to unit length, channel-major (B,256,S) (csrc/seed_ops.hip: p2r_vote_finish)."""
+
+    @staticmethod
+    def forward(ctx, net, seed_features, hip):
+        net, sf, hip = net.contiguous(), seed_features.contiguous(), hip.contiguous()
+        B, S, _ = sf.shape
+        dev = sf.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        xyz, feat, inv = torch.empty((B, S, 3), **f32), torch.empty((B, 256, S), **f32), torch.empty((B, S), **f32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().p2r_vote_finish(B, S, 256, _lib.ptr(net), _lib.ptr(sf), _lib.ptr(hip), _lib.ptr(xyz),
+                                                  _lib.ptr(feat), _lib.ptr(inv), _lib.current_stream(dev)), "vote_finish")
+        ctx.save_for_backward(feat, inv)
+        ctx.set_materialize_grads(False)
+        return xyz, feat
+
+    @staticmethod
+    def backward(ctx, d_xyz, d_feat):
+        feat, inv = ctx.saved_tensors
+        B, _, S = feat.shape
+        dev = feat.device
+        d_net = torch.empty((B, S, 259), dtype=torch.float32, device=dev)
+        d_sf = torch.empty((B, S, 256), dtype=torch.float32, device=dev)
+        d_xyz = d_xyz.contiguous() if d_xyz is not None else None
+        d_feat = d_feat.contiguous() if d_feat is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().p2r_vote_finish_grad(B, S, 256, _lib.ptr(d_xyz), _lib.ptr(d_feat), _lib.ptr(feat),
+                                                       _lib.ptr(inv), _lib.ptr(d_net), _lib.ptr(d_sf),
+                                                       _lib.current_stream(dev)), "vote_finish_grad")
+        return d_net, d_sf, d_xyz          # hip: vote_xyz = hip + offset
+
+
+def votes_normalized(module, seed_xyz, seed_features):
+    """CenterVoteModule.forward followed by the feature normalisation of P2RNet (network.py:68-71) on the fused path:
+    -> vote_xyz (B,S,3), vote_features (B,S,256) of unit length -- the latter a transposed view of channel-major
+    memory, so `features.transpose(1, 2).contiguous()` in front of the vote aggregation is free."""
+    net = vote_head(module, seed_features)                     # (B,259,S) view of (B,S,259) memory
+    hip = seed_xyz[:, :, module.origin_joint_id]
+    xyz, feat = _VoteFinish.apply(net.transpose(1, 2), seed_features, hip)
+    return xyz, feat.transpose(1, 2)
+
+
+def votes_normalized_supported(module, seed_xyz, seed_features):
+    return (vote_head_supported(module, seed_features) and module.vote_factor == 1
+            and module.conv_input[2].conv.out_channels == 259 and seed_xyz.dim() == 4 and seed_xyz.is_cuda
+            and seed_xyz.dtype == torch.float32)

@@ -357,3 +357,37 @@ def test_embed3_statistics_from_input_moments(dev):
         mean, var, _ = bn_op.moments(stats, B * L)
         assert _rel(mean, ref.mean((0, 2))) < 1e-6
         assert _rel(var, ref.var((0, 2), unbiased=False)) < 1e-5
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_votes_normalized_match_module_chain(dev, train):
+    """the whole voting stage of P2RNet._votes (conv_input, offset / residual adds, unit-length normalisation, channel-major
+    re-layout) fused vs the module chain + torch ops: values, layout contract and every gradient"""
+    from tests.test_model_cpu import build
+    from pose2room_amd.p2rnet import pw_op
+    from pose2room_amd.p2rnet.modules import vote_center
+    net, cfg = build('train', 256, device=dev)
+    mod = net.centervoting.to(dev)
+    ref = _clone_module(mod)
+    mod.train(train), ref.train(train)
+    B, S = 3, 512
+    seed_xyz = _rand((B, S, 53, 3), 1, dev).requires_grad_(True)
+    seed_xyz_r = seed_xyz.detach().clone().requires_grad_(True)
+    feats = _rand((B, S, 256), 2, dev).requires_grad_(True)
+    feats_r = feats.detach().clone().requires_grad_(True)
+    gx, gf = _rand((B, S, 3), 3, dev), _rand((B, 256, S), 4, dev)
+    assert pw_op.votes_normalized_supported(mod, seed_xyz, feats)
+    xyz, f = pw_op.votes_normalized(mod, seed_xyz, feats)
+    assert f.shape == (B, S, 256) and f.transpose(1, 2).is_contiguous()
+    (xyz * gx).sum().add((f.transpose(1, 2) * gf).sum()).backward()
+    vote_center.USE_FUSED_HEAD = False
+    try:
+        xyz_r, f_r = ref(seed_xyz_r, feats_r)
+        f_r = f_r.div(torch.norm(f_r, p=2, dim=2).unsqueeze(2))
+        (xyz_r * gx).sum().add((f_r.transpose(1, 2) * gf).sum()).backward()
+    finally:
+        vote_center.USE_FUSED_HEAD = True
+    assert _rel(xyz, xyz_r) < 1e-5 and _rel(f, f_r) < 1e-5
+    assert _rel(feats.grad, feats_r.grad) < 2e-4 and _rel(seed_xyz.grad, seed_xyz_r.grad) < 1e-6
+    for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert _rel(p.grad, q.grad) < 2e-4, n
