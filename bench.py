@@ -134,6 +134,11 @@ _TIMED = {
     'p2r_stgcn_tconv3_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
     'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
     'p2r_stgcn_tconv_weight_grad': lambda a: 'tconv_weight_grad' if a[3] == 3 else None,
+    # vote / proposal heads on the job-list kernels (csrc/pw_layers.hip): in-step time only
+    'p2r_pw_gemm': lambda a: 'heads_pw_gemm',
+    'p2r_pw_wgrad': lambda a: 'heads_pw_wgrad',
+    'p2r_sa_votes_forward': lambda a: 'vote_aggregation_forward',
+    'p2r_sa_votes_backward': lambda a: 'vote_aggregation_backward',
 }
 
 
@@ -152,6 +157,8 @@ def issued_mfma_flops(batch, frames):
     tiles16 = batch * ((frames + 15) // 16)
     per_rec = 4 * 16 * 2048.0                       # one record = 16 MFMAs in each of the 4 channel phases
     # (the statically scheduled kernel and the run-time work stream split long lists the same way: same step count)
+    if not tables.gen2:      # another skeleton: no work stream to count from (the first-generation kernels serve it)
+        return {}, 0.0, 0.0
     out = {'gcn_forward': int(tables.stream_c[:, hdr].sum()) * per_rec * tiles16,
            'gcn_data_gradient': int(tables.stream_r[:, hdr].sum()) * per_rec * tiles16}
     out.update(gcn_op.grad_kernel_mfma_flops(tables, batch, frames))
@@ -181,12 +188,16 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
                 'tflops': round(tf, 2), 'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
 
     rows = {tag: row(tag) for tag in sorted(per) if tag in issued}
+    for tag in sorted(per):          # kernels timed without a FLOP model: total in-step time per step
+        if tag not in issued:
+            ms_, n_ = per[tag]
+            rows[tag] = {'ms_in_step_total': round(ms_ * n_ / steps, 4), 'launches_per_step': n_ // steps}
     g2 = [t for t in ('gcn_forward', 'gcn_data_gradient') if t in per]
     n_g2 = sum(per[t][1] for t in g2)
     ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
     fl = sum(issued[t] * per[t][1] for t in g2) / n_g2
     tf = fl / ms / 1e9
-    traffic = _profile_json('r3_gcn3_pmc_traffic.json') or _profile_json('r2_gcn2_pmc_traffic.json')
+    traffic = _profile_json('r4_gcn3_pmc_traffic.json') or _profile_json('r3_gcn3_pmc_traffic.json')
     cols = batch_size * frames * 53
     scale = cols / float(32 * 1024 * 53)
     from pose2room_amd.p2rnet import gcn_op
@@ -211,7 +222,7 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
 def step_mfma_issued(batch, frames):
     """MFMA FLOPs the step's kernels issue (SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP/cycle/SIMD summed over one step, PMC
     profile from tools/pmc_step_mfma.sh at bs=32, T=1024; linear in batch * frames).  (flops, source) or (None, None)."""
-    for name in ('r3_step_mfma.json', 'r2_step_mfma.json'):
+    for name in ('r4_step_mfma.json', 'r3_step_mfma.json', 'r2_step_mfma.json'):
         prof = _profile_json(name)
         if prof:
             return prof['mfma_busy_cycles_per_step'] * 64.0 * (batch * frames) / float(32 * 1024), 'profiles/' + name
@@ -482,6 +493,9 @@ def main():
             'bound': 'mfma', 'achieved': round(ex_tf, 2) if issued else None, 'peak': FP32_MFMA_PEAK_TFLOPS * world,
             'unit': 'TFLOP/s', 'frac': round(ex_tf / FP32_MFMA_PEAK_TFLOPS, 4) if issued else None,
             'scope': f'whole train step of one rank: MFMA FLOPs issued per step ({src}) / step time',
+            'derived': 'the FLOP count is a stored PMC measurement (SQ_VALU_MFMA_BUSY_CYCLES x 64 summed over one step of '
+                       'the build that profile was taken on, at bs=32, T=1024, scaled by batch x frames), not a counter '
+                       'read in this run; the step time is this run\'s',
             'frac_reference_algorithmic': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
             'reference_algorithmic': f'{gflop_per_sample(args.frames)} GFLOP/sample fwd+bwd of the REFERENCE step (dense '
                                      'graph product), the count rounds 1-2 quoted as `frac`'}

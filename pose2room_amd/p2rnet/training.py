@@ -55,9 +55,18 @@ class _ScalarFetch(object):
     _pinned = {}
 
     def __init__(self, loss_dict):
-        self.names = list(loss_dict.keys())
+        names = self._keys = list(loss_dict.keys())
         with torch.no_grad():     # float32 -> float64 is exact, so the numbers equal `.item()` of each entry
-            vals = torch.stack([loss_dict[k].detach().double() for k in self.names])
+            # one stack per dtype and one conversion per group instead of one conversion launch per entry
+            groups = {}
+            for k in names:
+                groups.setdefault(loss_dict[k].dtype, []).append(k)
+            parts, order = [], []
+            for dt, ks in groups.items():
+                parts.append(torch.stack([loss_dict[k].detach().reshape(()) for k in ks]).double())
+                order += ks
+            vals = parts[0] if len(parts) == 1 else torch.cat(parts)
+        self.names = order
         self.event = None
         if vals.is_cuda:
             key = (vals.device, len(self.names))
@@ -74,7 +83,8 @@ class _ScalarFetch(object):
     def result(self):
         if self.event is not None:
             self.event.synchronize()
-        return dict(zip(self.names, self.vals.tolist()))
+        got = dict(zip(self.names, self.vals.tolist()))
+        return {k: got[k] for k in self._keys}
 
 
 def _split_by_optim_spec(net):
