@@ -410,6 +410,22 @@ int p2r_embed3_forward_stats(int N, int L, const float *x, const float *W, const
 int p2r_embed3_weight_grad(int N, int L, const float *x, const float *dout, float *partial,
                            void *stream);
 
+/* p2r_embed3_weight_grad with the output gradient in its BatchNorm-backward form coef[0][c] g + coef[1][c] z + coef[2][c]
+ * (g = masked gradient, z = the layer's saved output, both (N,64,L); coef [3][64]), formed while the tensors are read. */
+int p2r_embed3_weight_grad_lazy(int N, int L, const float *x, const float *g, const float *z, const float *coef,
+                                float *partial, void *stream);
+
+/* One-pass backward of a pointwise 64 -> 64 layer of the embedding MLPs (stgcn.py:46-63) behind a BatchNorm + ReLU
+ * (csrc/embed_bwd.hip): dz = coef ? coef[0] g + coef[1] z + coef[2] : g is the gradient of the layer's conv output
+ * (g, z (N,64,L), coef [3][64]); the layer's input is relu(zp * fin[2] + fin[3]) (zp (N,64,L) = the previous layer's conv
+ * output, fin [4][64] = mean, invstd, scale, shift of its BatchNorm); W [64][64] = the Conv1d weight [out][in].
+ * Outputs: g_prev (N,64,L) = (W^T dz) where the input is positive else 0; sums [n_blocks][64][2] = per-workgroup
+ * (sum g_prev, sum g_prev * (zp - mean) * invstd); dw_part [n_blocks][64][64] and db_part [n_blocks][64] (optional):
+ * per-workgroup partials of dW [out][in] and of the bias gradient.  L % 64 == 0, tensors 16-byte aligned. */
+int p2r_embed_layer_backward(int N, int L, const float *g, const float *z, const float *coef, const float *zp,
+                             const float *fin, const float *W, float *g_prev, float *sums, int n_blocks,
+                             float *dw_part, float *db_part, void *stream);
+
 /* per-row column sums: x viewed as [rows][T][V] -> out_partial [rows][V] = sum over T
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */
 int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream);

@@ -155,17 +155,28 @@ __global__ __launch_bounds__(256) void embed3_stats_kernel(int P, const float *_
 }
 
 // partial[row = n*64 + c] = (sum dout*x0, sum dout*x1, sum dout*x2, sum dout)
+// z / coef (both or neither): dout is then the BatchNorm-backward form coef[0][c] dout + coef[1][c] z + coef[2][c] of a
+// masked gradient and the layer's saved output z (csrc/embed_bwd.hip), formed on the fly.
 __global__ __launch_bounds__(EM_THREADS) void embed3_wgrad_kernel(int L, const float *__restrict__ x,
                                                                   const float *__restrict__ dout,
-                                                                  float4 *__restrict__ partial) {
-  const int row = blockIdx.x, n = row / EM_C;
+                                                                  float4 *__restrict__ partial,
+                                                                  const float *__restrict__ z,
+                                                                  const float *__restrict__ coef) {
+  const int row = blockIdx.x, n = row / EM_C, ch = row - n * EM_C;
   const float *dr = dout + (size_t)row * L;
+  const float *zr = z ? z + (size_t)row * L : nullptr;
+  const float ca = coef ? coef[ch] : 1.f, cb = coef ? coef[EM_C + ch] : 0.f, cc = coef ? coef[2 * EM_C + ch] : 0.f;
   const float *xn = x + (size_t)n * 3 * L;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   const bool vec = (L % 4 == 0);
   const int L4 = vec ? L >> 2 : 0;
   for (int i = threadIdx.x; i < L4; i += EM_THREADS) {
-    const float4 g = reinterpret_cast<const float4 *>(dr)[i];
+    float4 g = reinterpret_cast<const float4 *>(dr)[i];
+    if (zr) {
+      const float4 zz = reinterpret_cast<const float4 *>(zr)[i];
+      g.x = ca * g.x + cb * zz.x + cc; g.y = ca * g.y + cb * zz.y + cc;
+      g.z = ca * g.z + cb * zz.z + cc; g.w = ca * g.w + cb * zz.w + cc;
+    }
     const float4 a = reinterpret_cast<const float4 *>(xn)[i];
     const float4 b = reinterpret_cast<const float4 *>(xn + L)[i];
     const float4 c = reinterpret_cast<const float4 *>(xn + 2 * (size_t)L)[i];
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(EM_THREADS) void embed3_wgrad_kernel(int L, const f
     s[3] += (g.x + g.y) + (g.z + g.w);
   }
   for (int i = (L4 << 2) + threadIdx.x; i < L; i += EM_THREADS) {
-    const float g = dr[i];
+    const float g = zr ? ca * dr[i] + cb * zr[i] + cc : dr[i];
     s[0] += g * xn[i]; s[1] += g * xn[L + i]; s[2] += g * xn[2 * (size_t)L + i]; s[3] += g;
   }
   __shared__ float red[EM_THREADS / 64][4];
@@ -233,7 +244,19 @@ extern "C" int p2r_embed3_weight_grad(int N, int L, const float *x, const float 
   if (N < 0 || L <= 0) return P2R_EINVAL;
   if (N == 0) return P2R_OK;
   hipLaunchKernelGGL(embed3_wgrad_kernel, dim3(N * EM_C), dim3(EM_THREADS), 0, p2r_stream(stream), L, x, dout,
-                     reinterpret_cast<float4 *>(partial));
+                     reinterpret_cast<float4 *>(partial), (const float *)nullptr, (const float *)nullptr);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// the same with the output gradient in its BatchNorm-backward form: dout := coef[0][c] g + coef[1][c] z + coef[2][c]
+// (g, z (N,64,L); coef [3][64]), formed while g and z are read -- the gradient of the layer's output is never stored.
+extern "C" int p2r_embed3_weight_grad_lazy(int N, int L, const float *x, const float *g, const float *z, const float *coef,
+                                           float *partial, void *stream) {
+  if (N < 0 || L <= 0 || !z || !coef) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  hipLaunchKernelGGL(embed3_wgrad_kernel, dim3(N * EM_C), dim3(EM_THREADS), 0, p2r_stream(stream), L, x, g,
+                     reinterpret_cast<float4 *>(partial), z, coef);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

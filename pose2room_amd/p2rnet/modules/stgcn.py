@@ -81,7 +81,10 @@ class STGCN(nn.Module):
         On the GPU: the 3->64 layer is a streaming kernel, and each BatchNorm+ReLU is folded into the
         following pointwise 64->64 convolution (one pass per layer instead of GEMM + normalise +
         activate); elsewhere the plain module chain runs."""
-        from .. import bn_op, tconv_op
+        from .. import bn_op, tconv_op, embed_op
+        if embed_op.supported(seq, x, inner, add_ct):
+            # one autograd function for the stack: forward on the same kernels, backward one pass per layer
+            return embed_op.embed_mlp(seq, x, inner, add_ct)
         s0, s1, s2 = seq
         fused = (x.is_cuda and len(seq) == 3 and hasattr(s0, 'batchnorm') and hasattr(s1, 'batchnorm')
                  and not hasattr(s2, 'batchnorm') and tconv_op.supported_embed3(x, s0.conv)

@@ -253,3 +253,65 @@ def test_tconv3_equals_tconv2(dev, N, T, taps):
                 assert torch.equal(a, b)
     finally:
         tconv_op.USE_GEN3 = True
+
+
+@pytest.mark.parametrize("B,rows,inner,add", [(2, 64, 53, True), (3, 16, 20, False), (1, 128, 53, False), (2, 48, 20, True),
+                                              (2, 64, 64, True)])
+@pytest.mark.parametrize("train", [True, False])
+def test_embed_mlp_one_pass_backward(dev, B, rows, inner, add, train):
+    """embed_op.embed_mlp (forward on the tconv_op kernels, backward one fused pass per layer: csrc/embed_bwd.hip) against
+    (1) the module chain in fp64 for the output and the running statistics, and (2) the layer-by-layer functions of tconv_op
+    (data gradient, BatchNorm-backward apply, weight gradient as separate passes -- themselves pinned to fp64 chains by the
+    tests above) for every gradient.  Both fp32 paths run the same forward kernels, so they agree on every ReLU mask bit; an
+    fp64 chain does not: a pre-activation within fp32 rounding of zero (|y| = 6e-8 was seen at one of 434,176 positions)
+    flips one bit and moves a per-channel gradient sum by a whole element (1 % of a BatchNorm bias gradient)."""
+    from pose2room_amd.p2rnet import embed_op
+    from pose2room_amd.p2rnet.modules.stgcn import _point_mlp, STGCN
+    L = rows * inner
+    torch.manual_seed(B * 100 + rows + inner)
+    seq = _point_mlp(3, 64, 64).to(dev)
+    with torch.no_grad():
+        for m in seq.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 2.0)
+    ref64, lay = copy.deepcopy(seq).double(), copy.deepcopy(seq)
+    seq.train(train); ref64.train(train); lay.train(train)
+    x = torch.randn(B, 3, L, device=dev) * torch.tensor([1.0, 0.4, 2.0], device=dev)[None, :, None]
+    pe = torch.randn(B, 64, rows, device=dev).requires_grad_(True) if add else None
+    pel = pe.detach().clone().requires_grad_(True) if add else None
+    go = torch.randn(B, 64, L, device=dev)
+    assert embed_op.supported(seq, x, inner, pe)
+    out = embed_op.embed_mlp(seq, x, inner, pe)
+    out.backward(go)
+    embed_op.USE_FUSED = False
+    try:
+        out_l = STGCN._mlp(lay, x, inner, add_ct=pel)
+        out_l.backward(go)
+    finally:
+        embed_op.USE_FUSED = True
+    with torch.no_grad():
+        o64 = ref64(x.double())
+        if add:
+            o64 = (o64.view(B, 64, rows, inner) + pe.detach().double().unsqueeze(-1)).view(B, 64, L)
+
+    def close(a, b, what, tol):
+        scale = b.abs().max().item() + 1e-12
+        err = (a.double() - b.double()).abs().max().item()
+        assert err <= tol * scale, f"{what}: {err:.3e} vs {scale:.3e}"
+
+    close(out, o64, "out vs fp64", 5e-5)
+    if inner == 53:     # statically scheduled kernels: deterministic, the two paths agree bit for bit
+        assert torch.equal(out, out_l), "same forward kernels: same bits"
+    else:               # first-generation kernels merge their statistics with LDS float atomics: last-bit differences
+        close(out, out_l, "out vs layered", 2e-6)
+    if add:
+        close(pe.grad, pel.grad, "d_add", 1e-6)
+    for (n, p), (_, q) in zip(seq.named_parameters(), lay.named_parameters()):
+        assert p.grad is not None and q.grad is not None, n
+        close(p.grad, q.grad, n, 1e-4)
+    for (n, a_), (_, b_) in zip(seq.named_buffers(), lay.named_buffers()):
+        close(a_.float(), b_.float(), n, 0.0 if inner == 53 else 2e-6)
+    if train:
+        for (n, a_), (_, b_) in zip(seq.named_buffers(), ref64.named_buffers()):
+            close(a_.float(), b_.float(), n + " vs fp64", 2e-5)
