@@ -600,6 +600,11 @@ int p2r_vote_finish(int b, int s, int C, const float *net, const float *seed_fea
 int p2r_vote_finish_grad(int b, int s, int C, const float *d_xyz, const float *d_feat, const float *feat_ncl,
                          const float *inv_norm, float *d_net, float *d_sf, void *stream);
 
+/* seed selection by arc length (stgcn.py:96-101): inds[b,s] = the FIRST t minimising |cum[b,t] - target[b,s]| (fp32, the
+ * expression of `torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)` without its (b,t,s) tensor).
+ * cum (b,t), target (b,s) f32; inds (b,s) int64; t <= 40000. */
+int p2r_nearest_prefix(int b, int t, int s, const float *cum, const float *target, long long *inds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -474,19 +474,25 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(int P, long long M4, c
                                                           float *__restrict__ out, int tr64) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M4) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // eight rows in flight, two interleaved accumulators per component (rows p, p+2, .. and p+1, p+3, ..) combined at the
+  // end: the summation order is fixed (deterministic) and the rounding error grows with P / 2 instead of P
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
   int p = 0;
   for (; p + 8 <= P; p += 8) {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = ld_stream(reinterpret_cast<const float *>(in + (size_t)(p + u) * M4 + i));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    for (int u = 0; u < 8; u += 2) {
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+      acc2.x += v[u + 1].x; acc2.y += v[u + 1].y; acc2.z += v[u + 1].z; acc2.w += v[u + 1].w;
+    }
   }
   for (; p < P; ++p) {
     const float4 v = in[(size_t)p * M4 + i];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
+  acc.x += acc2.x; acc.y += acc2.y; acc.z += acc2.z; acc.w += acc2.w;
   if (!tr64) {
     reinterpret_cast<float4 *>(out)[i] = acc;
   } else {

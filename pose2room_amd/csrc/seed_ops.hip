@@ -181,6 +181,29 @@ __global__ __launch_bounds__(256) void vote_finish_grad_kernel(int S, const floa
   }
 }
 
+// ---- seed selection by arc length (stgcn.py:96-101) --------------------------------------------------------------------
+// inds[b, s] = argmin_t |cum[b, t] - target[b, s]| (first minimum), exactly the fp32 expression torch evaluates
+// (`torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)`) without the (B, T, S) difference tensor:
+// the cumulative arc length of a sample sits in LDS, a thread walks it for one target.
+__global__ __launch_bounds__(256) void nearest_prefix_kernel(int T, int S, const float *__restrict__ cum,
+                                                             const float *__restrict__ target,
+                                                             long long *__restrict__ inds) {
+  extern __shared__ float row[];
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < T; t += 256) row[t] = cum[(size_t)b * T + t];
+  __syncthreads();
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const float tg = target[(size_t)b * S + s];
+  float best = fabsf(row[0] - tg);
+  int arg = 0;
+  for (int t = 1; t < T; ++t) {
+    const float d = fabsf(row[t] - tg);
+    if (d < best) { best = d; arg = t; }          // strict: the first minimum wins, like argmin; NaN never wins
+  }
+  inds[(size_t)b * S + s] = arg;
+}
+
 }  // namespace
 
 // x (b, c, t, j) f32, inds (b, s) int64 frame indices -> out (b, s, c * j): out[b, s, ci * j + ji] = x[b, ci, inds[b, s], ji]
@@ -247,6 +270,17 @@ extern "C" int p2r_vote_finish_grad(int b, int s, int C, const float *d_xyz, con
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(vote_finish_grad_kernel, dim3((unsigned)((size_t)b * s / VF_COLS)), dim3(256), lds, p2r_stream(stream),
                      s, d_xyz, d_feat, feat_ncl, inv_norm, d_net, d_sf);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// inds[b, s] = first t minimising |cum[b, t] - target[b, s]| in fp32; cum (b,t), target (b,s) f32, inds (b,s) int64.
+extern "C" int p2r_nearest_prefix(int b, int t, int s, const float *cum, const float *target, long long *inds,
+                                  void *stream) {
+  if (b < 0 || t <= 0 || s < 0 || t > 40000) return P2R_EINVAL;
+  if (b == 0 || s == 0) return P2R_OK;
+  hipLaunchKernelGGL(nearest_prefix_kernel, dim3((unsigned)((s + 255) / 256), (unsigned)b), dim3(256),
+                     (size_t)t * sizeof(float), p2r_stream(stream), t, s, cum, target, inds);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -99,9 +99,13 @@ def permute_planes(W3):
 USE_GEN3 = True      # statically scheduled kernel for the P2RNet skeleton (tests switch it off to reach gcn2)
 
 
-def _gen3_able(x, z, addend, tables):
-    return (USE_GEN3 and tables.gen3 and x.shape[2] % 16 == 0 and x.data_ptr() % 16 == 0 and z.data_ptr() % 16 == 0
-            and (addend is None or addend.data_ptr() % 16 == 0))
+def _gen3_able(x, z, addend, tables, bwd=None):
+    """Everything p2r_stgcn_gcn3_forward checks before it launches (P2R_EINVAL otherwise), so that a shape or alignment
+    it does not take falls back to the second generation instead of raising: whole 16-frame tiles, 16-byte aligned
+    rows of x / z / addend / the saved activation of the BatchNorm-backward epilogue, 4-byte aligned mask bytes."""
+    return (USE_GEN3 and tables.gen3 and x.shape[0] > 0 and x.shape[2] % 16 == 0 and x.data_ptr() % 16 == 0
+            and z.data_ptr() % 16 == 0 and (addend is None or addend.data_ptr() % 16 == 0)
+            and (bwd is None or (bwd[0].data_ptr() % 16 == 0 and bwd[1].data_ptr() % 4 == 0)))
 
 
 def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None, form=None):
@@ -116,7 +120,7 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
     ltot = coef.shape[0]
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
-        gen3 = form is not None and _gen3_able(x, z, addend, tables)
+        gen3 = form is not None and _gen3_able(x, z, addend, tables, bwd)
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256); forward launches of
             #                 the third generation write (count, mean, M2) entries, everything else pairs of sums
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 3 if gen3 and bwd is None else 2),
@@ -206,7 +210,8 @@ class _GraphConv(Function):
                 part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
                 # the bias-table gradient (column sums of dz) rides on the same pass over dz
                 bpart = torch.empty((_N_BLOCKS, C, V), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
-                if USE_GEN3 and tables.gen3 and T % 4 == 0 and x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0:
+                if (USE_GEN3 and tables.gen3 and N > 0 and T % 4 == 0 and x.data_ptr() % 16 == 0
+                        and dz.data_ptr() % 16 == 0):      # (N == 0: the first-generation kernel returns zeros)
                     # statically scheduled kernel (csrc/stgcn_gcn3_dw.hip)
                     _lib.check(lib.p2r_stgcn_gcn3_weight_grad(
                         N, T, V, K, coef_r.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(coef_r.contiguous()), _N_BLOCKS,

@@ -71,6 +71,9 @@ class STGCN(nn.Module):
                                dim=1).float()
             stride = cum[:, -1] / (self.n_seeds - 1)
             target = stride.unsqueeze(-1) * torch.arange(self.n_seeds, dtype=torch.float, device=device)
+            if cum.is_cuda and cum.dtype == torch.float32 and n_frames <= 40000:
+                from .. import seed_op
+                return seed_op.nearest_prefix(cum, target)      # same fp32 expression, first minimum, one launch
             return torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)
         raise NotImplementedError
 

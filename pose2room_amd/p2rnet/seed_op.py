@@ -98,3 +98,17 @@ class _AddBroadcastLast(Function):
 
 def add_broadcast_last(a, b):
     return _AddBroadcastLast.apply(a, b)
+
+
+def nearest_prefix(cum, target):
+    """cum (B,T), target (B,S) f32 on the GPU -> (B,S) int64: first index t minimising |cum[b,t] - target[b,s]| -- what
+    `torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)` returns, in one launch and without the
+    (B,T,S) tensor."""
+    cum, target = cum.contiguous(), target.contiguous()
+    B, T = cum.shape
+    S = target.shape[1]
+    out = torch.empty((B, S), dtype=torch.int64, device=cum.device)
+    with torch.cuda.device(cum.device):
+        _lib.check(_lib.lib().p2r_nearest_prefix(B, T, S, _lib.ptr(cum), _lib.ptr(target), _lib.ptr(out),
+                                                 _lib.current_stream(cum.device)), "nearest_prefix")
+    return out

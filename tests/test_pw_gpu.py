@@ -391,3 +391,24 @@ def test_votes_normalized_match_module_chain(dev, train):
     assert _rel(feats.grad, feats_r.grad) < 2e-4 and _rel(seed_xyz.grad, seed_xyz_r.grad) < 1e-6
     for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
         assert _rel(p.grad, q.grad) < 2e-4, n
+
+
+def test_nearest_prefix_equals_argmin_of_abs_difference(dev):
+    """seed selection by arc length: the kernel must return torch.argmin's index for every target, incl. plateaus of the
+    cumulative arc length (repeated frames: exact ties, first index wins) and targets exactly between two prefixes."""
+    from pose2room_amd.p2rnet import seed_op
+    g = torch.Generator().manual_seed(9)
+    for B, T, S in ((4, 256, 512), (3, 1024, 512), (2, 341, 100), (1, 2048, 512)):
+        step = torch.rand(B, T - 1, generator=g)
+        step[torch.rand(B, T - 1, generator=g) < 0.3] = 0.0              # plateaus
+        step = (step * 8).round() / 8                                     # exactly representable: exact mid-point ties
+        cum = torch.cumsum(torch.cat([torch.zeros(B, 1), step], 1).double(), 1).float().to(dev)
+        stride = cum[:, -1] / (S - 1)
+        target = stride.unsqueeze(-1) * torch.arange(S, dtype=torch.float, device=dev)
+        want = torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)
+        # torch's own contract: the first minimum (checked on the host so that the test does not depend on the device reduce)
+        d = torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)).cpu()
+        first = torch.stack([torch.tensor([int((d[b, :, s] == d[b, :, s].min()).nonzero()[0]) for s in range(S)]) for b in range(B)])
+        got = seed_op.nearest_prefix(cum, target)
+        assert torch.equal(got.cpu(), first)
+        assert torch.equal(got, want)
