@@ -126,6 +126,7 @@ def _null(a):
 # entry point -> tag of the launch (None: not timed).  Argument positions as in include/p2r_hip.h.
 _TIMED = {
     'p2r_stgcn_gcn3_forward': lambda a: None if _null(a[11]) else ('gcn_data_gradient' if a[5] == 1 else 'gcn_forward'),
+    'p2r_stgcn_gcn3_data_gradient_masked_addend': lambda a: 'gcn_data_gradient',
     'p2r_stgcn_gcn3_coef_grad': lambda a: 'gcn_coef_grad',
     'p2r_stgcn_gcn3_weight_grad': lambda a: 'gcn_weight_grad',
     'p2r_stgcn_gcn2_forward': lambda a: None if _null(a[12]) else ('gcn_data_gradient' if _null(a[10]) else 'gcn_forward'),

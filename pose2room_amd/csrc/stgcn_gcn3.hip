@@ -184,11 +184,14 @@ __device__ __forceinline__ void g3_mfma16(f32x4 (&acc)[4], const float (&a)[4][4
 // of a workgroup may meet at different program counters.
 // BWD (data-gradient launches): the statistics epilogue emits the reduction pass of the BatchNorm + residual + ReLU
 // backward of the block in front, exactly as gcn2_kernel<.., true> does (see stgcn_gcn2.hip).
-template <int FORM, bool BWD, int WAVE>
+// MADD (BWD launches): the addend is masked on the way in -- addend * (addend_mask != 0) -- i.e. the residual-branch
+// gradient g = dout * relu_mask of the block is formed here from the incoming gradient and the mask bytes instead of
+// being written (444 MB at bs=32, T=1024) by the BatchNorm-backward pass and read back.
+template <int FORM, bool BWD, int WAVE, bool MADD = false>
 __device__ __forceinline__ void g3_wave_main(
     const G3Params &p, float *lds, const float *__restrict__ x, const float *__restrict__ Wp,
     const float *__restrict__ addend, float *__restrict__ z, bool want_stats, const float *__restrict__ bwd_u,
-    const unsigned char *__restrict__ bwd_mask) {
+    const unsigned char *__restrict__ bwd_mask, const unsigned char *__restrict__ addend_mask = nullptr) {
   constexpr int V = G3_V, RS = G3_RS, BUF = G3_BUF, NW = G3_NW, SLOTS = G3_SLOTS;
   constexpr int wave = WAVE;
   float *rowstat = lds + 2 * BUF;                                         // [NW][64][G3_ST]
@@ -252,6 +255,7 @@ __device__ __forceinline__ void g3_wave_main(
     const float *ag = addend ? addend + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const float *ug = BWD ? bwd_u + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const unsigned char *mg = BWD ? bwd_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
+    const unsigned char *amg = (BWD && MADD) ? addend_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * G3_F : 0;
@@ -349,17 +353,20 @@ __device__ __forceinline__ void g3_wave_main(
       float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
       float4 ad[BWD ? 2 : 1][BWD ? RIT : 1];
       unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
+      unsigned mk2[(BWD && MADD) ? 2 : 1][(BWD && MADD) ? RIT : 1];
       auto load_bwd = [&](int m, int rr) {
         const size_t r0 = (size_t)(16 * m + 2 * wave + rr) * row_stride;
         const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
         const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
         const float4 *a4 = reinterpret_cast<const float4 *>(ag ? ag + r0 : nullptr);
+        const unsigned *am4 = reinterpret_cast<const unsigned *>((BWD && MADD) ? amg + r0 : nullptr);
 #pragma unroll
         for (int it = 0; it < (BWD ? RIT : 1); ++it) {
           const int c4 = it * 64 + lane;
           uv[BWD ? rr : 0][it] = c4 < R4 ? u4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
           mk[BWD ? rr : 0][it] = c4 < R4 ? m4[c4] : 0u;
           if (a4 && c4 < R4) ad[BWD ? rr : 0][it] = a4[c4];
+          if (BWD && MADD) mk2[(BWD && MADD) ? rr : 0][it] = c4 < R4 ? am4[c4] : 0u;
         }
       };
       if (BWD) { load_bwd(0, 0); load_bwd(0, 1); }
@@ -390,7 +397,15 @@ __device__ __forceinline__ void g3_wave_main(
               const int c4 = it * 64 + lane;
               if (c4 < R4) {
                 float4 v = srow[row * R4 + c4];
-                if (arow) { v.x += ad[rr][it].x; v.y += ad[rr][it].y; v.z += ad[rr][it].z; v.w += ad[rr][it].w; }
+                if (arow) {
+                  if (BWD && MADD) {
+                    const unsigned m2 = mk2[(BWD && MADD) ? rr : 0][it];
+                    v.x += (m2 & 0xffu) ? ad[rr][it].x : 0.f; v.y += (m2 & 0xff00u) ? ad[rr][it].y : 0.f;
+                    v.z += (m2 & 0xff0000u) ? ad[rr][it].z : 0.f; v.w += (m2 & 0xff000000u) ? ad[rr][it].w : 0.f;
+                  } else {
+                    v.x += ad[rr][it].x; v.y += ad[rr][it].y; v.z += ad[rr][it].z; v.w += ad[rr][it].w;
+                  }
+                }
                 zrow[(size_t)row * (row_stride / 4) + c4] = v;
                 const float4 uu = uv[rr][it];
                 const unsigned mm = mk[rr][it];
@@ -436,12 +451,12 @@ __device__ __forceinline__ void g3_wave_main(
 
 }
 
-template <int FORM, bool BWD>
+template <int FORM, bool BWD, bool MADD = false>
 __global__ __launch_bounds__(G3_NW * 64, 2) void gcn3_kernel(
     G3Params p, int ltot, const float *__restrict__ x, const float *__restrict__ Wp, const float *__restrict__ coef,
     const float *__restrict__ bias_cv, const float *__restrict__ addend, float *__restrict__ z,
     float *__restrict__ stats_partial, const float *__restrict__ bwd_u, const unsigned char *__restrict__ bwd_mask,
-    const float *__restrict__ bwd_fin) {
+    const float *__restrict__ bwd_fin, const unsigned char *__restrict__ addend_mask) {
   constexpr int V = G3_V, BUF = G3_BUF, NW = G3_NW;
   extern __shared__ float lds[];
   float *rowstat = lds + 2 * BUF;
@@ -460,14 +475,14 @@ __global__ __launch_bounds__(G3_NW * 64, 2) void gcn3_kernel(
 
   const bool want_stats = stats_partial != nullptr;
   switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-    case 0: g3_wave_main<FORM, BWD, 0>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 1: g3_wave_main<FORM, BWD, 1>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 2: g3_wave_main<FORM, BWD, 2>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 3: g3_wave_main<FORM, BWD, 3>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 4: g3_wave_main<FORM, BWD, 4>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 5: g3_wave_main<FORM, BWD, 5>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    case 6: g3_wave_main<FORM, BWD, 6>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
-    default: g3_wave_main<FORM, BWD, 7>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask); break;
+    case 0: g3_wave_main<FORM, BWD, 0, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 1: g3_wave_main<FORM, BWD, 1, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 2: g3_wave_main<FORM, BWD, 2, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 3: g3_wave_main<FORM, BWD, 3, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 4: g3_wave_main<FORM, BWD, 4, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 5: g3_wave_main<FORM, BWD, 5, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    case 6: g3_wave_main<FORM, BWD, 6, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
+    default: g3_wave_main<FORM, BWD, 7, MADD>(p, lds, x, Wp, addend, z, want_stats, bwd_u, bwd_mask, addend_mask); break;
   }
 
   if (stats_partial) {
@@ -504,16 +519,17 @@ __global__ __launch_bounds__(G3_NW * 64, 2) void gcn3_kernel(
   }
 }
 
-template <int FORM, bool BWD>
+template <int FORM, bool BWD, bool MADD = false>
 int gcn3_launch(const G3Params &p, int ltot, int blocks, size_t lds, const float *x, const float *Wp, const float *coef,
                 const float *bias_cv, const float *addend, float *z, float *stats_partial, const float *bwd_u,
-                const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h) {
-  auto kern = gcn3_kernel<FORM, BWD>;
+                const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h,
+                const unsigned char *addend_mask = nullptr) {
+  auto kern = gcn3_kernel<FORM, BWD, MADD>;
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(kern, lds_ok);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(G3_NW * 64), lds, p2r_stream(stream_h), p, ltot, x, Wp, coef, bias_cv, addend,
-                     z, stats_partial, bwd_u, bwd_mask, bwd_fin);
+                     z, stats_partial, bwd_u, bwd_mask, bwd_fin, addend_mask);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -531,10 +547,11 @@ extern "C" unsigned long long p2r_stgcn_gcn3_signature(int form) {
 // table the schedule indexes (values of A * importance at the list entries, zeros at padded slots).
 // Requirements beyond gcn2's (P2R_EINVAL otherwise; the caller then uses gcn2): T % 16 == 0 and x, z, addend 16-byte
 // aligned.  n_partials: number of workgroups = rows of stats_partial (call with z == NULL to query).
-extern "C" int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const float *x, const float *Wp,
-                                      const float *coef, const float *bias_cv, const float *addend, float *z,
-                                      float *stats_partial, int *n_partials, const float *bwd_u,
-                                      const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h) {
+static int gcn3_forward_impl(int N, int T, int V, int K, int ltot, int form, const float *x, const float *Wp,
+                             const float *coef, const float *bias_cv, const float *addend, float *z,
+                             float *stats_partial, int *n_partials, const float *bwd_u,
+                             const unsigned char *bwd_mask, const float *bwd_fin, const unsigned char *addend_mask,
+                             void *stream_h) {
   if (N < 0 || T <= 0 || V != G3_V || K != G3_K || ltot <= 0 || (form != 0 && form != 1)) return P2R_EINVAL;
   if (T % G3_F != 0 || T > (1 << 20)) return P2R_EINVAL;
   const bool bwd = bwd_u != nullptr;
@@ -559,8 +576,36 @@ extern "C" int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int 
     return gcn3_launch<0, false>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, nullptr, nullptr,
                                  nullptr, stream_h);
   }
+  if (addend_mask) {     // addend masked on the way in: only with the BatchNorm-backward epilogue (the ST-GCN chain)
+    if (!bwd || !addend || ((uintptr_t)addend_mask % 4) != 0) return P2R_EINVAL;
+    return gcn3_launch<1, true, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, bwd_u, bwd_mask,
+                                      bwd_fin, stream_h, addend_mask);
+  }
   if (bwd) return gcn3_launch<1, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, bwd_u, bwd_mask,
                                        bwd_fin, stream_h);
   return gcn3_launch<1, false>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, nullptr, nullptr, nullptr,
                                stream_h);
+}
+
+extern "C" int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const float *x, const float *Wp,
+                                      const float *coef, const float *bias_cv, const float *addend, float *z,
+                                      float *stats_partial, int *n_partials, const float *bwd_u,
+                                      const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h) {
+  return gcn3_forward_impl(N, T, V, K, ltot, form, x, Wp, coef, bias_cv, addend, z, stats_partial, n_partials, bwd_u, bwd_mask,
+                           bwd_fin, nullptr, stream_h);
+}
+
+// The data-gradient launch with the BatchNorm-backward epilogue (form 1, bwd_* given) whose addend is MASKED on the way
+// in: z += addend where addend_mask (N,64,T,53 bytes) is non-zero.  With addend = the gradient arriving at a block's
+// output and addend_mask = that block's ReLU mask this is the residual-branch gradient dout * mask, which the
+// BatchNorm-backward pass then does not have to write.  addend_mask 4-byte aligned.
+extern "C" int p2r_stgcn_gcn3_data_gradient_masked_addend(int N, int T, int V, int K, int ltot, const float *x,
+                                                          const float *Wp, const float *coef, const float *addend,
+                                                          const unsigned char *addend_mask, float *z,
+                                                          float *stats_partial, const float *bwd_u,
+                                                          const unsigned char *bwd_mask, const float *bwd_fin,
+                                                          void *stream_h) {
+  if (!addend_mask) return P2R_EINVAL;
+  return gcn3_forward_impl(N, T, V, K, ltot, 1, x, Wp, coef, nullptr, addend, z, stats_partial, nullptr, bwd_u, bwd_mask,
+                           bwd_fin, addend_mask, stream_h);
 }

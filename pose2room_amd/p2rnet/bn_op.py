@@ -129,11 +129,28 @@ class BNLink(object):
                 self.versions == (self.u._version, self.mask._version, self.fin._version))
 
 
+# Residual-branch gradients handed over UNMASKED (see `_FusedBNAct.backward`): (data_ptr, version) of the tensor -> the ReLU
+# mask bytes it still has to be multiplied with.  The consumer (gcn_op._GraphConv.backward) takes the entry out.
+_LAZY_RES = {}
+
+
+def take_lazy_res(t):
+    """The mask that belongs to residual gradient `t`, if `t` was handed over unmasked; removes the entry."""
+    if t is None:
+        return None
+    return _LAZY_RES.pop((t.data_ptr(), t._version), None)
+
+
 class _FusedBNAct(Function):
-    """Train-mode BatchNorm (+res) (+ReLU).  `fin` [4, C] = (mean, invstd, scale, shift) from `finalize`."""
+    """Train-mode BatchNorm (+res) (+ReLU).  `fin` [4, C] = (mean, invstd, scale, shift) from `finalize`.
+
+    lazy_res (only when `res` is the identity branch handed out by gcn_op.graph_conv(with_residual=True), whose backward is
+    the one consumer of its gradient): the residual gradient g = dy * mask is not written by the backward apply pass; the
+    incoming gradient dy itself is returned for `res` and registered in `_LAZY_RES` with the mask bytes, and the graph
+    conv's data-gradient kernel multiplies while it adds (444 MB less written and as many fewer read per block)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, fin, relu, link=None):
+    def forward(ctx, x, weight, bias, res, fin, relu, link=None, lazy_res=False):
         x = x.contiguous()
         res_c = res.contiguous() if res is not None else None
         # the ReLU mask is kept as one byte per element, so the backward does not re-read y (4 bytes) twice
@@ -141,6 +158,7 @@ class _FusedBNAct(Function):
         ctx.save_for_backward(x, mask, fin)
         ctx.relu = relu
         ctx.has_res = res is not None
+        ctx.lazy_res = bool(lazy_res) and relu and res is not None
         ctx.link = link if relu else None
         if ctx.link is not None:
             link.attach(x, mask, fin)
@@ -170,13 +188,16 @@ class _FusedBNAct(Function):
                                                  _lib.current_stream(dev)), "bn_bwd_reduce")
         tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        dres = torch.empty_like(x) if (ctx.has_res and not ctx.lazy_res) else None
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
                                             mode, None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
-        return dx, tot[1], tot[0], dres, None, None, None
+        if ctx.lazy_res:
+            _LAZY_RES[(dy.data_ptr(), dy._version)] = mask
+            dres = dy
+        return dx, tot[1], tot[0], dres, None, None, None, None
 
 
 class _EvalBNAct(Function):
@@ -210,13 +231,14 @@ def supported(x, bn):
     return x.is_cuda and x.dtype == torch.float32 and bn.affine and bn.track_running_stats and x.dim() >= 3
 
 
-def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None):
+def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None, lazy_res=False):
     """stats: optional kernel partials [P, C, 3 | 2] of x (see `moments`) replacing the statistics pass.
-    link: a `BNLink` to hang on the result (train mode) for the graph conv that consumes it."""
+    link: a `BNLink` to hang on the result (train mode) for the graph conv that consumes it.
+    lazy_res: see `_FusedBNAct` (train mode only)."""
     if bn.training:
         part = _stats_partial(x.contiguous()) if stats is None else stats
         fin = finalize(part, x.numel() // x.shape[1], bn)
-        y = _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu, link)
+        y = _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu, link, lazy_res)
         if link is not None and relu:
             y._p2r_bn_link = link
         return y

@@ -108,7 +108,8 @@ def _gen3_able(x, z, addend, tables, bwd=None):
             and (bwd is None or (bwd[0].data_ptr() % 16 == 0 and bwd[1].data_ptr() % 4 == 0)))
 
 
-def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None, form=None):
+def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend=None, bwd=None, form=None,
+                  addend_mask=None):
     """bwd = (u, mask, fin): data-gradient launch whose statistics epilogue is the reduction pass of the
     BatchNorm + residual + ReLU backward of the block in front (implies want_stats; see bn_op.BNLink).
     form: 0 column lists (forward) / 1 row lists (data gradient) when known -- the statically scheduled third-generation
@@ -121,10 +122,21 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
         gen3 = form is not None and _gen3_able(x, z, addend, tables, bwd)
+        if addend_mask is not None and not (gen3 and bwd is not None and form == 1 and addend_mask.data_ptr() % 4 == 0):
+            # the masked-addend form exists only in the statically scheduled data-gradient kernel with the
+            # BatchNorm-backward epilogue: anywhere else the product is formed here (one elementwise launch)
+            addend = addend * (addend_mask != 0)
+            addend_mask = None
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256); forward launches of
             #                 the third generation write (count, mean, M2) entries, everything else pairs of sums
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 3 if gen3 and bwd is None else 2),
                                dtype=torch.float32, device=x.device)
+        if gen3 and addend_mask is not None:
+            _lib.check(lib.p2r_stgcn_gcn3_data_gradient_masked_addend(
+                N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef), _lib.ptr(addend), _lib.ptr(addend_mask),
+                _lib.ptr(z), _lib.ptr(part), _lib.ptr(bwd[0]), _lib.ptr(bwd[1]), _lib.ptr(bwd[2].contiguous()), st),
+                "stgcn_gcn3_data_gradient_masked_addend")
+            return (z, part) if want_stats else z
         if gen3:
             bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
             _lib.check(lib.p2r_stgcn_gcn3_forward(N, T, V, tables.K, ltot, int(form), _lib.ptr(x), _lib.ptr(Wp),
@@ -144,7 +156,7 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
 class _GraphConv(Function):
     @staticmethod
     def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False,
-                bn_link=None, wp_f=None, wp_b=None):
+                bn_link=None, wp_f=None, wp_b=None, lazy_res=False):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
@@ -162,6 +174,7 @@ class _GraphConv(Function):
         ctx.wp_b = wp_b            # planes of the data gradient, already in kernel order (prepare_chain), or None
         ctx.wp_f = wp_f            # forward planes in kernel order: the adjacency-gradient kernel multiplies by them
         ctx.n_out = 2 if want_stats else 1
+        ctx.lazy_res = bool(lazy_res) and with_residual     # the identity branch's gradient arrives unmasked (bn_op._LAZY_RES)
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         if with_residual:
@@ -174,6 +187,14 @@ class _GraphConv(Function):
     def backward(ctx, dz, *rest):
         x, W, coef_c, coef_r = ctx.saved_tensors
         dres = rest[ctx.n_out - 1] if len(rest) >= ctx.n_out else None     # gradient of the identity branch, if any
+        dres_mask = None
+        if ctx.lazy_res and dres is not None:
+            from . import bn_op
+            dres = dres.contiguous()
+            dres_mask = bn_op.take_lazy_res(dres)
+            if dres_mask is None:
+                raise RuntimeError("graph_conv: the identity branch's gradient was announced unmasked (lazy_res) but no "
+                                   "mask is registered for it -- the residual has another consumer than this op")
         tables = ctx.tables
         dev = x.device
         t = tables.on(dev)
@@ -190,7 +211,7 @@ class _GraphConv(Function):
                 dx = _gcn2_forward(dz, wp_b, coef_r.contiguous(),
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,
                                    want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None,
-                                   form=1)
+                                   form=1, addend_mask=dres_mask)
                 if use_link:
                     # dx is the whole gradient of the previous block's output: its BatchNorm backward takes the
                     # two per-channel sums from here instead of a pass over dx and its saved input
@@ -198,6 +219,8 @@ class _GraphConv(Function):
                     link.grad_ptr, link.grad_version = dx.data_ptr(), dx._version
                 dres = None
             else:
+                if dres_mask is not None:
+                    dres, dres_mask = dres * (dres_mask != 0), None
                 Wt = W.view(K, C, C).transpose(1, 2).contiguous()            # [k][ci][c]
                 dx = _gcn_forward(dz, Wt, t['nbr_r'], coef_r.contiguous(), tables.LkA_r, None, tables)
         lib = _lib.lib()
@@ -246,8 +269,10 @@ class _GraphConv(Function):
                 _lib.check(lib.p2r_colsum(N * C, T, V, _lib.ptr(dz), _lib.ptr(part), st), "colsum")
             dbias = part.view(N, C, V).sum(0)                          # (C, V)
         if dres is not None:
+            if dres_mask is not None:
+                dres = dres * (dres_mask != 0)
             dx = dres if dx is None else dx + dres
-        return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None
+        return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None, None
 
 
 def grad_kernel_mfma_flops(tables, batch, frames):
@@ -287,7 +312,8 @@ def supported(x, weight, A):
             and A.shape[1] <= 56)      # the weight-gradient kernel stages 4 frames x V <= 226 columns per row
 
 
-def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None, prepared=None):
+def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None, prepared=None,
+               lazy_res=False):
     """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
     with_residual: additionally return x itself (last output) for the caller's identity branch; its gradient is then
     added inside the data-gradient kernel.
@@ -297,20 +323,23 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
     through this call (x and, with_residual, the identity branch): the data-gradient kernel then also emits the
     reduction pass of that BatchNorm's backward.
     prepared: this block's `BlockParams` from `prepare_chain` (coefficient tables, bias table and kernel-order
-    planes computed for all blocks at once); Aeff is then not looked at."""
+    planes computed for all blocks at once); Aeff is then not looked at.
+    lazy_res (with_residual): the identity branch goes into `bn_op.fused_bn_act(..., lazy_res=True)`, whose backward hands
+    its gradient over unmasked; this op's data-gradient kernel applies the mask while it adds."""
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)
     if prepared is not None:
         return _GraphConv.apply(x, w2, prepared.coef_c, prepared.coef_r, prepared.bias_cv, tables, want_stats,
-                                with_residual, bn_link, prepared.gcn_wp_f, prepared.gcn_wp_b)
+                                with_residual, bn_link, prepared.gcn_wp_f, prepared.gcn_wp_b, lazy_res)
     coef_c = gcn_tables.coefficients(Aeff.detach(), t['gidx_c'])      # forward lists (values only)
     coef_r = gcn_tables.coefficients(Aeff, t['gidx_r'])               # backward lists; carries the gradient to Aeff
     if bias is not None:
         bias_cv = bias.view(K, 64).t() @ Aeff.sum(dim=1)               # (64,V) = sum_k b_k (x) colsum_k
     else:
         bias_cv = torch.zeros(64, V, dtype=x.dtype, device=x.device)
-    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual, bn_link)
+    return _GraphConv.apply(x, w2, coef_c, coef_r, bias_cv, tables, want_stats, with_residual, bn_link, None, None,
+                            lazy_res)
 
 
 class BlockParams(object):

@@ -111,7 +111,7 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None, prepared=None):
+    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None, prepared=None, lazy_res=False):
         """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
         following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv).  with_residual (same
         path): x itself comes back as the last element of the tuple, for the caller's identity branch.
@@ -121,7 +121,7 @@ class ConvTemporalGraphical(nn.Module):
             from .. import gcn_op
             if gcn_op.supported(x, self.conv.weight, A):
                 return gcn_op.graph_conv(x, self.conv.weight, self.conv.bias, A, self.tables, want_stats,
-                                         with_residual, bn_link, prepared), A
+                                         with_residual, bn_link, prepared, lazy_res), A
         assert not want_stats and not with_residual and prepared is None
         y = self.conv(x)
         n, kc, t, v = y.size()
@@ -166,6 +166,7 @@ class st_gcn_block(nn.Module):
 
     fused_bn = True   # BatchNorm + residual + ReLU on the fused HIP kernels (GPU tensors)
     fused_tconv = True   # BatchNorm + ReLU + temporal conv in one kernel
+    lazy_residual_grad = True   # chain path: the residual gradient dout * mask is formed inside the graph-conv data gradient
     chain_input = False  # set by the owner when this block is the ONLY consumer of its input (the previous block's
                          # output): the data-gradient kernel then also serves that block's BatchNorm backward
 
@@ -186,19 +187,24 @@ class st_gcn_block(nn.Module):
             # kernel epilogues hand the batch statistics to the BatchNorm that follows (train mode)
             chain = self.chainable(x, A)
             assert chain or prepared is None
+            lazy = False
             if chain:
                 if self.residual is _iden and x.requires_grad:
                     # identity branch routed through the graph-conv op: its gradient is added inside the
-                    # data-gradient kernel instead of a separate accumulation pass over the activation
+                    # data-gradient kernel instead of a separate accumulation pass over the activation -- and, being
+                    # consumed there and nowhere else, it is handed over unmasked (bn_op._FusedBNAct, lazy_res): the
+                    # kernel multiplies by the ReLU mask while it adds
                     in_link = getattr(x, '_p2r_bn_link', None) if self.chain_input else None
+                    lazy = self.lazy_residual_grad and self.tcn[3].training      # (_FusedBNAct: train-mode BatchNorm only)
                     (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True, bn_link=in_link,
-                                                   prepared=prepared)
+                                                   prepared=prepared, lazy_res=lazy)
                 else:
                     (z, zstats), A = self.gcn(x, A, want_stats=True, prepared=prepared)
                 wp = (prepared.tcn_wp_f, prepared.tcn_wp_b) if prepared is not None and z.shape[3] == 53 else None
                 u, ustats = tconv_op.bn_relu_tconv(z, self.tcn[0], self.tcn[2], stats=zstats, want_stats=True, wp=wp)
                 res_t = res if torch.is_tensor(res) else None
-                return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats, link=bn_op.BNLink()), A
+                return bn_op.fused_bn_act(u, self.tcn[3], res_t, relu=True, stats=ustats, link=bn_op.BNLink(),
+                                          lazy_res=lazy), A
             x, A = self.gcn(x, A)
             if bn_op.supported(x, self.tcn[0]):
                 if self.fused_tconv and tconv_op.supported(x, self.tcn[0], self.tcn[2]):
