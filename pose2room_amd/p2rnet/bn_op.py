@@ -129,25 +129,31 @@ class BNLink(object):
                 self.versions == (self.u._version, self.mask._version, self.fin._version))
 
 
-# Residual-branch gradients handed over UNMASKED (see `_FusedBNAct.backward`): (data_ptr, version) of the tensor -> the ReLU
-# mask bytes it still has to be multiplied with.  The consumer (gcn_op._GraphConv.backward) takes the entry out.
-_LAZY_RES = {}
+class ResLink(object):
+    """Handshake for a residual-branch gradient that is handed over UNMASKED (see `_FusedBNAct`, lazy_res): the producer
+    (this BatchNorm + residual + ReLU's backward) leaves the ReLU mask bytes and the identity (address, version counter)
+    of the tensor it returned for the residual; the one consumer (gcn_op._GraphConv.backward of the same block) takes the
+    mask for exactly that tensor.  One link per block and forward pass; nothing global."""
+    __slots__ = ('mask', 'grad_ptr', 'grad_version')
 
+    def __init__(self):
+        self.mask = self.grad_ptr = self.grad_version = None
 
-def take_lazy_res(t):
-    """The mask that belongs to residual gradient `t`, if `t` was handed over unmasked; removes the entry."""
-    if t is None:
-        return None
-    return _LAZY_RES.pop((t.data_ptr(), t._version), None)
+    def take(self, t):
+        """the mask for residual gradient `t`, or None when `t` is not the tensor the producer announced"""
+        if t is None or self.mask is None or self.grad_ptr != t.data_ptr() or self.grad_version != t._version:
+            return None
+        mask, self.mask, self.grad_ptr, self.grad_version = self.mask, None, None, None
+        return mask
 
 
 class _FusedBNAct(Function):
     """Train-mode BatchNorm (+res) (+ReLU).  `fin` [4, C] = (mean, invstd, scale, shift) from `finalize`.
 
-    lazy_res (only when `res` is the identity branch handed out by gcn_op.graph_conv(with_residual=True), whose backward is
-    the one consumer of its gradient): the residual gradient g = dy * mask is not written by the backward apply pass; the
-    incoming gradient dy itself is returned for `res` and registered in `_LAZY_RES` with the mask bytes, and the graph
-    conv's data-gradient kernel multiplies while it adds (444 MB less written and as many fewer read per block)."""
+    lazy_res = a `ResLink` (only when `res` is the identity branch handed out by gcn_op.graph_conv(with_residual=True,
+    lazy_res=the same link), whose backward is the one consumer of its gradient): the residual gradient g = dy * mask is
+    not written by the backward apply pass; the incoming gradient dy itself is returned for `res`, the link carries the
+    mask bytes, and the graph conv's data-gradient kernel multiplies while it adds (444 MB less written per block)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, fin, relu, link=None, lazy_res=False):
@@ -158,7 +164,7 @@ class _FusedBNAct(Function):
         ctx.save_for_backward(x, mask, fin)
         ctx.relu = relu
         ctx.has_res = res is not None
-        ctx.lazy_res = bool(lazy_res) and relu and res is not None
+        ctx.lazy_res = lazy_res if (isinstance(lazy_res, ResLink) and relu and res is not None) else None
         ctx.link = link if relu else None
         if ctx.link is not None:
             link.attach(x, mask, fin)
@@ -188,14 +194,14 @@ class _FusedBNAct(Function):
                                                  _lib.current_stream(dev)), "bn_bwd_reduce")
         tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (ctx.has_res and not ctx.lazy_res) else None
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.lazy_res is None) else None
         with torch.cuda.device(dev):
             _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
                                             mode, None, None, _lib.ptr(dx), _lib.ptr(dres),
                                             _lib.current_stream(dev)), "bn_bwd_apply")
-        if ctx.lazy_res:
-            _LAZY_RES[(dy.data_ptr(), dy._version)] = mask
+        if ctx.lazy_res is not None:
+            ctx.lazy_res.mask, ctx.lazy_res.grad_ptr, ctx.lazy_res.grad_version = mask, dy.data_ptr(), dy._version
             dres = dy
         return dx, tot[1], tot[0], dres, None, None, None, None
 
@@ -231,10 +237,10 @@ def supported(x, bn):
     return x.is_cuda and x.dtype == torch.float32 and bn.affine and bn.track_running_stats and x.dim() >= 3
 
 
-def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None, lazy_res=False):
+def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None, lazy_res=None):
     """stats: optional kernel partials [P, C, 3 | 2] of x (see `moments`) replacing the statistics pass.
     link: a `BNLink` to hang on the result (train mode) for the graph conv that consumes it.
-    lazy_res: see `_FusedBNAct` (train mode only)."""
+    lazy_res: a `ResLink` shared with the graph conv that handed out `res`, see `_FusedBNAct` (train mode only)."""
     if bn.training:
         part = _stats_partial(x.contiguous()) if stats is None else stats
         fin = finalize(part, x.numel() // x.shape[1], bn)

@@ -156,7 +156,7 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
 class _GraphConv(Function):
     @staticmethod
     def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False,
-                bn_link=None, wp_f=None, wp_b=None, lazy_res=False):
+                bn_link=None, wp_f=None, wp_b=None, lazy_res=None):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
@@ -174,7 +174,7 @@ class _GraphConv(Function):
         ctx.wp_b = wp_b            # planes of the data gradient, already in kernel order (prepare_chain), or None
         ctx.wp_f = wp_f            # forward planes in kernel order: the adjacency-gradient kernel multiplies by them
         ctx.n_out = 2 if want_stats else 1
-        ctx.lazy_res = bool(lazy_res) and with_residual     # the identity branch's gradient arrives unmasked (bn_op._LAZY_RES)
+        ctx.lazy_res = lazy_res if with_residual else None  # bn_op.ResLink: the identity branch's gradient arrives unmasked
         if want_stats:
             ctx.mark_non_differentiable(out[1])
         if with_residual:
@@ -188,10 +188,9 @@ class _GraphConv(Function):
         x, W, coef_c, coef_r = ctx.saved_tensors
         dres = rest[ctx.n_out - 1] if len(rest) >= ctx.n_out else None     # gradient of the identity branch, if any
         dres_mask = None
-        if ctx.lazy_res and dres is not None:
-            from . import bn_op
+        if ctx.lazy_res is not None and dres is not None:
             dres = dres.contiguous()
-            dres_mask = bn_op.take_lazy_res(dres)
+            dres_mask = ctx.lazy_res.take(dres)
             if dres_mask is None:
                 raise RuntimeError("graph_conv: the identity branch's gradient was announced unmasked (lazy_res) but no "
                                    "mask is registered for it -- the residual has another consumer than this op")
@@ -313,7 +312,7 @@ def supported(x, weight, A):
 
 
 def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=False, bn_link=None, prepared=None,
-               lazy_res=False):
+               lazy_res=None):
     """x (N,64,T,V); weight (K*64,64[,1,1]); bias (K*64) or None; Aeff (K,V,V).
     with_residual: additionally return x itself (last output) for the caller's identity branch; its gradient is then
     added inside the data-gradient kernel.
@@ -324,8 +323,9 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
     reduction pass of that BatchNorm's backward.
     prepared: this block's `BlockParams` from `prepare_chain` (coefficient tables, bias table and kernel-order
     planes computed for all blocks at once); Aeff is then not looked at.
-    lazy_res (with_residual): the identity branch goes into `bn_op.fused_bn_act(..., lazy_res=True)`, whose backward hands
-    its gradient over unmasked; this op's data-gradient kernel applies the mask while it adds."""
+    lazy_res (with_residual): a `bn_op.ResLink` shared with the `bn_op.fused_bn_act(..., lazy_res=link)` the identity
+    branch goes into, whose backward hands its gradient over unmasked; this op's data-gradient kernel applies the mask
+    while it adds."""
     K, V = tables.K, tables.V
     t = tables.on(x.device)
     w2 = weight.reshape(K * 64, 64)

@@ -111,7 +111,7 @@ class ConvTemporalGraphical(nn.Module):
                               padding=(t_padding, 0), stride=(t_stride, 1), dilation=(t_dilation, 1),
                               bias=bias)
 
-    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None, prepared=None, lazy_res=False):
+    def forward(self, x, A, want_stats=False, with_residual=False, bn_link=None, prepared=None, lazy_res=None):
         """want_stats (fused GPU path only): return ((z, stats partials), A) -- the per-channel sums the
         following BatchNorm needs, produced by the kernel's epilogue (gcn_op.graph_conv).  with_residual (same
         path): x itself comes back as the last element of the tuple, for the caller's identity branch.
@@ -187,7 +187,7 @@ class st_gcn_block(nn.Module):
             # kernel epilogues hand the batch statistics to the BatchNorm that follows (train mode)
             chain = self.chainable(x, A)
             assert chain or prepared is None
-            lazy = False
+            lazy = None
             if chain:
                 if self.residual is _iden and x.requires_grad:
                     # identity branch routed through the graph-conv op: its gradient is added inside the
@@ -195,7 +195,8 @@ class st_gcn_block(nn.Module):
                     # consumed there and nowhere else, it is handed over unmasked (bn_op._FusedBNAct, lazy_res): the
                     # kernel multiplies by the ReLU mask while it adds
                     in_link = getattr(x, '_p2r_bn_link', None) if self.chain_input else None
-                    lazy = self.lazy_residual_grad and self.tcn[3].training      # (_FusedBNAct: train-mode BatchNorm only)
+                    if self.lazy_residual_grad and self.tcn[3].training:      # (_FusedBNAct: train-mode BatchNorm only)
+                        lazy = bn_op.ResLink()
                     (z, zstats, res), A = self.gcn(x, A, want_stats=True, with_residual=True, bn_link=in_link,
                                                    prepared=prepared, lazy_res=lazy)
                 else:
