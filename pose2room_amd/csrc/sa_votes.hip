@@ -47,7 +47,7 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ W, const floa
 }
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void sa_votes_kernel(int n, int m, float radius2, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256, 2) void sa_votes_kernel(int n, int m, float radius2, const float *__restrict__ xyz,
                                                        const float *__restrict__ new_xyz,
                                                        const float *__restrict__ features,
                                                        const float *__restrict__ w1, const float *__restrict__ b1,
@@ -56,8 +56,12 @@ __global__ __launch_bounds__(256) void sa_votes_kernel(int n, int m, float radiu
                                                        float *__restrict__ G, float *__restrict__ H,
                                                        unsigned char *__restrict__ amax) {
   extern __shared__ float lds[];
-  float *gs = lds;                         // [256][SA_RS] gathered features
-  float *hs = lds + SA_C * SA_RS;          // [256][SA_RS] hidden activation
+  // ONE [256][SA_RS] tile: the gathered features during the first product, the hidden activation afterwards (a barrier
+  // separates the last read of the one from the first write of the other).  With two tiles (139 KB) a CU held one
+  // workgroup and its ball query, gather and epilogues ran with the matrix pipe idle; with one (70 KB) two workgroups
+  // share a CU and one's products cover the other's serial phases.
+  float *gs = lds;
+  float *hs = lds;
   __shared__ int s_idx[SA_BALLS][SA_S];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256) void sa_votes_kernel(int n, int m, float radiu
   floatx4v acc[4][4];
   // ---- layer 1: hs = relu(W1 . gs + b1) --------------------------------------------------
   sa_layer(w1, gs, wave, g, r, acc);
+  __syncthreads();                         // every wave has finished reading the gathered features
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void sa_votes_kernel(int n, int m, float radiu
 // ---- backward of the two layers on the forward's tiling (4 balls = 64 columns per workgroup) -------------------
 // dout, out (B,256,M); amax u8 (B,256,M); H (B,256,M,16) saved by the training forward; w2t = W2^T, w1t = W1^T
 // (row = input channel of the layer).  Writes dZ2, dZ1, dG (B,256,M,16).
-__global__ __launch_bounds__(256) void sa_votes_backward_kernel(int m, const float *__restrict__ dout,
+__global__ __launch_bounds__(256, 2) void sa_votes_backward_kernel(int m, const float *__restrict__ dout,
                                                                 const float *__restrict__ out,
                                                                 const unsigned char *__restrict__ amax,
                                                                 const float *__restrict__ H,
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(256) void sa_votes_backward_kernel(int m, const flo
                                                                 float *__restrict__ dZ2, float *__restrict__ dZ1,
                                                                 float *__restrict__ dG) {
   extern __shared__ float lds[];
-  float *zs = lds;                         // [256][SA_RS] dZ2 tile, later dZ1
-  float *ys = lds + SA_C * SA_RS;          // [256][SA_RS] dZ1 tile
+  float *zs = lds;                         // [256][SA_RS] dZ2 tile ...
+  float *ys = lds;                         // ... and, after a barrier, the dZ1 tile in the same place (see the forward)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int groups = (m + SA_BALLS - 1) / SA_BALLS;
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(256) void sa_votes_backward_kernel(int m, const flo
   floatx4v acc[4][4];
   // dH = W2^T . dZ2 ;  dZ1 = dH * (H > 0)
   sa_layer(w2t, zs, wave, g, r, acc);
+  __syncthreads();                         // every wave has finished reading dZ2
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -299,7 +305,7 @@ extern "C" int p2r_sa_votes_forward(int b, int n, int m, int nsample, float radi
   if (nsample != SA_S || C0 != SA_C || C1 != SA_C || C2 != SA_C) return P2R_EINVAL;
   if (b == 0 || m == 0) return P2R_OK;
   const int groups = (m + SA_BALLS - 1) / SA_BALLS;
-  const size_t lds = 2 * (size_t)SA_C * SA_RS * sizeof(float);
+  const size_t lds = (size_t)SA_C * SA_RS * sizeof(float);
   auto kern = train ? sa_votes_kernel<true> : sa_votes_kernel<false>;
   static unsigned char lds_ok[2][P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(kern, lds_ok[train ? 1 : 0], (int)lds);
@@ -320,7 +326,7 @@ extern "C" int p2r_sa_votes_backward(int b, int m, int nsample, int C, const flo
   if (b < 0 || m < 0 || nsample != SA_S || C != SA_C) return P2R_EINVAL;
   if (b == 0 || m == 0) return P2R_OK;
   const int groups = (m + SA_BALLS - 1) / SA_BALLS;
-  const size_t lds = 2 * (size_t)SA_C * SA_RS * sizeof(float);
+  const size_t lds = (size_t)SA_C * SA_RS * sizeof(float);
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(sa_votes_backward_kernel, lds_ok, (int)lds);
   if (e != hipSuccess) return (int)e;

@@ -72,3 +72,8 @@ def fb():
     feat.grad = None
     sa(xyz, feat)[1].backward(go)
 print(f'sa module forward + backward             {timed(lambda: fb()):8.1f} us')
+
+with torch.no_grad():
+    print(f'sa module forward, inference (no G / H / arg-max stores) {timed(lambda: sa(xyz, feat)):8.1f} us')
+from pose2room_amd.pointnet2_ops import _ext
+print(f'fps alone                                 {timed(lambda: _ext.furthest_point_sampling(xyz, 128)):8.1f} us')
