@@ -195,7 +195,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   constexpr int HALO = (TAPS - 1) / 2;
   constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // rows and row pointers in SGPRs
   const int g = lane >> 4, r = lane & 15;
   const int nt = wave & 3, mh = wave >> 2;          // 16 ci columns x (64 / TW_MH) c rows per wave
   const int tiles_per_seq = (T + F - 1) / F;
@@ -219,38 +219,61 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   // tile has been written to LDS, so HBM latency and transfer hide under the MFMA phase (one workgroup per CU).
   constexpr int NR = TC_C / (TW_THREADS / 64);     // rows per wave: wave, wave + 8, ...
   float ph_[NR][NH], pd_[NR][4];
-  auto issue_loads = [&](int tile) {
+  // The loads of a tile are NH + 4 pieces per row, each ONE `buffer_load_dword` through a descriptor of the row built
+  // from wave-uniform values: the hardware range check returns zero for columns outside the tile or the tensor (a
+  // negative column wraps to a huge unsigned offset), so the load path has no predicate, no clamp and no exec-masked
+  // branch -- with one, hipcc's wait insertion put `s_waitcnt vmcnt(0)` in front of every piece.  issue_loads(tile)
+  // issues all pieces (the first tile); the fully unrolled instances issue ONE piece per reduction step of the
+  // current tile instead, so that no wave has to push 40 loads through a memory pipeline that all 256 workgroups
+  // fill at the same moment before it reaches its MFMAs.
+  constexpr int PIECES = NR * (NH + 4);
+  const int rs = (int)row_stride;           // T * V < 2^29 (checked by the launcher): 32-bit byte offsets inside a row
+  const int lane4 = lane * 4;
+  const float *ld_x = x, *ld_d = dout;
+  int ld_col0 = 0, ld_hcols = 0, ld_hbytes = 0, ld_dbytes = 0;
+  auto set_tile = [&](int tile, bool valid) __attribute__((always_inline)) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * F;
     const int frames = min(F, T - t0);
-    const int ncols = frames * V;
-    const float *xg = x + (size_t)seq * TC_C * row_stride;
-    const float *dg = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
-    const long long col0 = (long long)(t0 - HALO) * V;
-#pragma unroll
-    for (int hh = 0; hh < NR; ++hh) {
-      const int c = wave + hh * (TW_THREADS / 64);
-      const float *sx = xg + (size_t)c * row_stride;
-      const float *sd = dg + (size_t)c * row_stride;
-#pragma unroll
-      for (int i = 0; i < NH; ++i) {
-        const int q = lane + 64 * i;
-        const long long gc = col0 + q;
-        const bool in = q < (frames + 2 * HALO) * V && gc >= 0 && gc < (long long)row_stride;
-        ph_[hh][i] = in ? sx[in ? gc : 0] : __int_as_float(0x7fc00000);     // NaN marks "outside": becomes zero
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = lane + 64 * i;
-        pd_[hh][i] = q < ncols ? sd[q] : 0.f;
-      }
+    ld_hcols = (frames + 2 * HALO) * V;
+    ld_x = x + (size_t)seq * TC_C * row_stride;
+    ld_d = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+    ld_col0 = (t0 - HALO) * V;
+    ld_hbytes = valid ? 4 * min(rs, ld_col0 + ld_hcols) : 0;       // no next tile: every load returns zero
+    ld_dbytes = valid ? 4 * frames * V : 0;
+  };
+  auto issue_piece = [&](int j) __attribute__((always_inline)) {   // j = hh * (NH + 4) + i, a compile-time constant at every call site
+    const int hh = j / (NH + 4), i = j % (NH + 4);
+    const int c = wave + hh * (TW_THREADS / 64);
+    if (i < NH) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(ld_x + (size_t)c * row_stride), 0, ld_hbytes, 0x00020000);
+      ph_[hh][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + 4 * (ld_col0 + 64 * i), 0, 0));
+    } else {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(ld_d + (size_t)c * row_stride), 0, ld_dbytes, 0x00020000);
+      pd_[hh][i - NH] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + 256 * (i - NH), 0, 0));
     }
+  };
+  auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+    set_tile(tile, true);
+#pragma unroll
+    for (int hh = 0; hh < NR; ++hh)
+#pragma unroll
+      for (int i = 0; i < NH + 4; ++i) issue_piece(hh * (NH + 4) + i);
   };
 
   int tile = blockIdx.x;
   if (tile < total_tiles) issue_loads(tile);
   for (; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();                                   // previous tile fully consumed
+    // ld_* still describe the tile that sits in the registers
+    bool hin[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int q = lane + 64 * i, gc = ld_col0 + q;
+      hin[i] = q < ld_hcols && gc >= 0 && gc < rs;
+    }
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
       const int c = wave + hh * (TW_THREADS / 64);
@@ -260,8 +283,8 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
         float v = ph_[hh][i];
-        if (v != v) v = 0.f;
-        else if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        v = hin[i] ? v : 0.f;
         if (q < row_h) hs[c * row_h + q] = v;
       }
 #pragma unroll
@@ -271,7 +294,12 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < total_tiles) issue_loads(tile + gridDim.x);
+    const bool more = tile + (int)gridDim.x < total_tiles;
+    if constexpr (VS > 0) {
+      set_tile(more ? tile + gridDim.x : tile, more);
+    } else {
+      if (more) issue_loads(tile + gridDim.x);
+    }
 
     const float *drow = ds + (16 * TW_MT * mh + r) * row_d + g;  // + 16*m rows, + 4*s columns
     const float *hrow = hs + (16 * nt + r) * row_h + g;          // + p*V, + 4*s columns
@@ -281,11 +309,13 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
     for (int m = 0; m < TW_MT; ++m) a[m] = drow[16 * m * row_d];
     if constexpr (VS > 0) {
       constexpr int STEPS = (F * VS + 3) / 4;
+      static_assert(PIECES <= STEPS, "one piece of the next tile per reduction step");
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * VS];
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         float na[TW_MT], nb[TAPS];
+        if (s < PIECES) issue_piece(s);
 #pragma unroll
         for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
 #pragma unroll
@@ -399,6 +429,7 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   while (row_h % 32 != 2) ++row_h;
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
   if (lds > 160 * 1024 || F * V > 256 || (F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
+  if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
     hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F>, lds_ok);
