@@ -184,16 +184,24 @@ constexpr int TW_MT = 4 / (TW_WAVES / 4);     // 16-row c tiles per wave (waves 
 // VS = compile-time joint count (0: run time).  With VS fixed the reduction loop is fully unrolled and every
 // LDS read carries an immediate offset: no address arithmetic on the VALU, which on gfx950 does not overlap
 // with the partner waves' MFMAs.
+__host__ __device__ constexpr int tw_row(int cols) {   // + room for the last (partial) 4-column step and one prefetched
+  int r = cols + 7;                                    // step, then up to == 2 (mod 32): conflict-free column reads
+  while (r % 32 != 2) ++r;
+  return r;
+}
 template <int TAPS, int VS, int F = TW_F>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
-    int n_seq, int T, int V, int row_d, int row_h, const float *__restrict__ x,
+    int n_seq, int T, int V_, int row_d_, int row_h_, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
     float *__restrict__ dw_partial, float *__restrict__ dbias_partial) {
+  constexpr int HALO = (TAPS - 1) / 2;
+  constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
+  // joint count and row strides are compile-time constants in the fully unrolled instances (write predicates fold)
+  const int V = VS > 0 ? VS : V_;
+  const int row_d = VS > 0 ? tw_row(F * VS) : row_d_, row_h = VS > 0 ? tw_row((F + 2 * HALO) * VS) : row_h_;
   extern __shared__ float lds[];
   float *ds = lds;                       // [64][row_d]   dout tile, frames t0 .. t0+F-1
   float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-HALO .. t0+F-1+HALO
-  constexpr int HALO = (TAPS - 1) / 2;
-  constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // rows and row pointers in SGPRs
   const int g = lane >> 4, r = lane & 15;
@@ -423,10 +431,7 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
                            void *stream) {
   constexpr int HALO = (TAPS - 1) / 2;
-  int row_d = F * V + 7;                      // room for the last (partial) 4-column step + one prefetched step
-  while (row_d % 32 != 2) ++row_d;               // == 2 (mod 32): conflict-free column reads
-  int row_h = (F + 2 * HALO) * V + 7;
-  while (row_h % 32 != 2) ++row_h;
+  const int row_d = tw_row(F * V), row_h = tw_row((F + 2 * HALO) * V);
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
   if (lds > 160 * 1024 || F * V > 256 || (F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
   if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets

@@ -6,8 +6,8 @@ from pose2room_amd import _lib
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 st = _lib.current_stream(dev)
-def t(fn, reps=10):
-    for _ in range(3): fn()
+def t(fn, reps=40):
+    for _ in range(20): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()
