@@ -363,6 +363,17 @@ int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const float *x, c
                                 const float *shift, const float *dout, int n_blocks,
                                 float *dw_partial, float *dbias_partial, void *stream);
 
+/* The same launch with the BatchNorm-backward apply pass of the convolution's INPUT BatchNorm riding on its tile
+ * staging (V = 53, taps = 3 only; P2R_EINVAL otherwise).  Replaces p2r_bn_bwd_apply(relu = 2) + the launch above in
+ * the backward of `tcn` = BatchNorm2d, ReLU, Conv2d((3,1)) (stgcn_layers.py:399-412):
+ *   dz[n,c,t,w] = scale[c] * ((x * scale[c] + shift[c] > 0 ? dh : 0) - m1[c] - (x - mean[c]) * invstd[c] * m2[c])
+ * dh = gradient w.r.t. the BatchNorm-ReLU output (the data gradient of the convolution); fin [4][64] = mean, invstd,
+ * scale, shift (p2r_bn_finalize); m12 [2][64] = m1, m2 (rows 2, 3 of p2r_bn_bwd_finalize; zeros in evaluation mode).
+ * dz must not alias x or dh. */
+int p2r_stgcn_tconv_weight_grad_dz(int N, int T, int V, int taps, const float *x, const float *fin,
+                                   const float *dout, const float *dh, const float *m12, float *dz, int n_blocks,
+                                   float *dw_partial, float *dbias_partial, void *stream);
+
 /* Second generation of p2r_stgcn_tconv_forward for V = 53, taps = 3 (temporal conv) or 1 (the pointwise
  * 64 -> 64 convolutions of the embedding MLPs; Wp [1][4][4][64][4]) (csrc/stgcn_tconv2.hip): MFMA n-tile = 16
  * frames of one joint, channel phases double-buffered in LDS by LDS-DMA, persistent workgroups, input transform

@@ -189,16 +189,25 @@ __host__ __device__ constexpr int tw_row(int cols) {   // + room for the last (p
   while (r % 32 != 2) ++r;
   return r;
 }
-template <int TAPS, int VS, int F = TW_F>
+// DZ: the launch also forms the gradient of the BatchNorm INPUT on its way -- the tile already holds z (the h tile
+// is relu(z * scale + shift)), so with the gradient dh of the BatchNorm-ReLU output loaded next to it
+//   dz = scale * ((z * scale + shift > 0 ? dh : 0) - m1 - (z - mean) * invstd * m2)       (bn_bwd_apply, mask form 2)
+// leaves from the staging pass and the separate apply pass (read dh, read z, write dz) is gone: one more read and
+// one write of the tensor in a kernel that leaves two thirds of the HBM rate unused.
+template <int TAPS, int VS, int F = TW_F, bool DZ = false>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V_, int row_d_, int row_h_, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
-    float *__restrict__ dw_partial, float *__restrict__ dbias_partial) {
+    float *__restrict__ dw_partial, float *__restrict__ dbias_partial, const float *__restrict__ dh = nullptr,
+    const float *__restrict__ fin = nullptr, const float *__restrict__ m12 = nullptr, float *__restrict__ dz = nullptr) {
   constexpr int HALO = (TAPS - 1) / 2;
   constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
   // joint count and row strides are compile-time constants in the fully unrolled instances (write predicates fold)
   const int V = VS > 0 ? VS : V_;
   const int row_d = VS > 0 ? tw_row(F * VS) : row_d_, row_h = VS > 0 ? tw_row((F + 2 * HALO) * VS) : row_h_;
+  static_assert(!DZ || VS > 0, "the fused BatchNorm-backward form exists for the unrolled instances");
+  // chunks of the h row that hold columns of the tile's own frames (the ones dz is formed for)
+  constexpr int ZI0 = DZ ? (HALO * VS) / 64 : 0, ZI1 = DZ ? ((HALO + F) * VS - 1) / 64 : -1, NZ = ZI1 - ZI0 + 1;
   extern __shared__ float lds[];
   float *ds = lds;                       // [64][row_d]   dout tile, frames t0 .. t0+F-1
   float *hs = lds + TC_C * row_d;        // [64][row_h]   h tile, frames t0-HALO .. t0+F-1+HALO
@@ -226,41 +235,46 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   // Persistent loop with register prefetch: the global loads of the NEXT tile are issued right after the current
   // tile has been written to LDS, so HBM latency and transfer hide under the MFMA phase (one workgroup per CU).
   constexpr int NR = TC_C / (TW_THREADS / 64);     // rows per wave: wave, wave + 8, ...
-  float ph_[NR][NH], pd_[NR][4];
-  // The loads of a tile are NH + 4 pieces per row, each ONE `buffer_load_dword` through a descriptor of the row built
-  // from wave-uniform values: the hardware range check returns zero for columns outside the tile or the tensor (a
+  float ph_[NR][NH], pd_[NR][4], pz_[NR][NZ > 0 ? NZ : 1];
+  // The loads of a tile are NH + 4 (+ NZ) pieces per row, each ONE `buffer_load_dword` through a descriptor of the row
+  // built from wave-uniform values: the hardware range check returns zero for columns outside the tile or the tensor (a
   // negative column wraps to a huge unsigned offset), so the load path has no predicate, no clamp and no exec-masked
   // branch -- with one, hipcc's wait insertion put `s_waitcnt vmcnt(0)` in front of every piece.  issue_loads(tile)
-  // issues all pieces (the first tile); the fully unrolled instances issue ONE piece per reduction step of the
+  // issues all pieces (the first tile); the fully unrolled instances spread them over the reduction steps of the
   // current tile instead, so that no wave has to push 40 loads through a memory pipeline that all 256 workgroups
   // fill at the same moment before it reaches its MFMAs.
-  constexpr int PIECES = NR * (NH + 4);
+  constexpr int PER_ROW = NH + 4 + NZ, PIECES = NR * PER_ROW;
   const int rs = (int)row_stride;           // T * V < 2^29 (checked by the launcher): 32-bit byte offsets inside a row
   const int lane4 = lane * 4;
-  const float *ld_x = x, *ld_d = dout;
-  int ld_col0 = 0, ld_hcols = 0, ld_hbytes = 0, ld_dbytes = 0;
+  size_t ld_off = 0;                        // element offset of the tile's sequence
+  int ld_t0v = 0, ld_col0 = 0, ld_hcols = 0, ld_hbytes = 0, ld_dbytes = 0, ld_zbytes = 0;
   auto set_tile = [&](int tile, bool valid) __attribute__((always_inline)) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * F;
     const int frames = min(F, T - t0);
     ld_hcols = (frames + 2 * HALO) * V;
-    ld_x = x + (size_t)seq * TC_C * row_stride;
-    ld_d = dout + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
+    ld_off = (size_t)seq * TC_C * row_stride;
+    ld_t0v = t0 * V;
     ld_col0 = (t0 - HALO) * V;
     ld_hbytes = valid ? 4 * min(rs, ld_col0 + ld_hcols) : 0;       // no next tile: every load returns zero
     ld_dbytes = valid ? 4 * frames * V : 0;
+    ld_zbytes = valid ? 4 * (ld_t0v + frames * V) : 0;             // dh / dz: up to the end of the tile's own frames
   };
-  auto issue_piece = [&](int j) __attribute__((always_inline)) {   // j = hh * (NH + 4) + i, a compile-time constant at every call site
-    const int hh = j / (NH + 4), i = j % (NH + 4);
+  auto issue_piece = [&](int j) __attribute__((always_inline)) {   // j = hh * PER_ROW + i, a compile-time constant at every call site
+    const int hh = j / PER_ROW, i = j % PER_ROW;
     const int c = wave + hh * (TW_THREADS / 64);
+    const size_t row = ld_off + (size_t)c * row_stride;
     if (i < NH) {
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float *>(ld_x + (size_t)c * row_stride), 0, ld_hbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + row), 0, ld_hbytes, 0x00020000);
       ph_[hh][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + 4 * (ld_col0 + 64 * i), 0, 0));
-    } else {
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float *>(ld_d + (size_t)c * row_stride), 0, ld_dbytes, 0x00020000);
+    } else if (i < NH + 4) {
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dout + row + ld_t0v), 0, ld_dbytes, 0x00020000);
       pd_[hh][i - NH] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + 256 * (i - NH), 0, 0));
+    } else {
+      const int iz = i - NH - 4;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dh + row), 0, ld_zbytes, 0x00020000);
+      pz_[hh][iz] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4 + 4 * (ld_col0 + 64 * (ZI0 + iz)), 0, 0));
     }
   };
   auto issue_loads = [&](int tile) __attribute__((always_inline)) {
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh)
 #pragma unroll
-      for (int i = 0; i < NH + 4; ++i) issue_piece(hh * (NH + 4) + i);
+      for (int i = 0; i < PER_ROW; ++i) issue_piece(hh * PER_ROW + i);
   };
 
   int tile = blockIdx.x;
@@ -287,6 +301,23 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       const int c = wave + hh * (TW_THREADS / 64);
       const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
       bsum[hh] += (pd_[hh][0] + pd_[hh][1]) + (pd_[hh][2] + pd_[hh][3]);
+      if constexpr (DZ) {
+        const float mu = fin[c], is = fin[64 + c], kk = sc, a1 = m12[c], a2 = m12[64 + c];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            dz + ld_off + (size_t)c * row_stride, 0, ld_zbytes, 0x00020000);
+#pragma unroll
+        for (int iz = 0; iz < NZ; ++iz) {
+          const int i = ZI0 + iz;
+          const float zv = ph_[hh][i];
+          const float gq = fmaf(zv, sc, sh) > 0.f ? pz_[hh][iz] : 0.f;
+          const float xh = (zv - mu) * is;
+          const float o = kk * (gq - a1 - xh * a2);
+          // columns of the halo frame in front (chunk ZI0 only) are another tile's; past the tile's last frame the
+          // descriptor drops the store
+          if (64 * i >= HALO * VS || lane + 64 * i >= HALO * VS)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rsrc, lane4 + 4 * (ld_col0 + 64 * i), 0, 0);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
@@ -317,13 +348,15 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
     for (int m = 0; m < TW_MT; ++m) a[m] = drow[16 * m * row_d];
     if constexpr (VS > 0) {
       constexpr int STEPS = (F * VS + 3) / 4;
-      static_assert(PIECES <= STEPS, "one piece of the next tile per reduction step");
+      constexpr int PPS = (PIECES + STEPS - 1) / STEPS;          // pieces of the next tile per reduction step
 #pragma unroll
       for (int p = 0; p < TAPS; ++p) b[p] = hrow[p * VS];
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         float na[TW_MT], nb[TAPS];
-        if (s < PIECES) issue_piece(s);
+#pragma unroll
+        for (int k = 0; k < PPS; ++k)
+          if (PPS * s + k < PIECES) issue_piece(PPS * s + k);
 #pragma unroll
         for (int m = 0; m < TW_MT; ++m) na[m] = drow[16 * m * row_d + 4 * s + 4];
 #pragma unroll
@@ -426,10 +459,11 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const floa
                    : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream);
 }
 
-template <int TAPS, int VS, int F = TW_F>
+template <int TAPS, int VS, int F = TW_F, bool DZ = false>
 static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
-                           void *stream) {
+                           void *stream, const float *dh = nullptr, const float *fin = nullptr, const float *m12 = nullptr,
+                           float *dz = nullptr) {
   constexpr int HALO = (TAPS - 1) / 2;
   const int row_d = tw_row(F * V), row_h = tw_row((F + 2 * HALO) * V);
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
@@ -437,11 +471,11 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
-    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F>, lds_ok);
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, DZ>, lds_ok);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T, V,
-                     row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial);
+  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, DZ>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T,
+                     V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin, m12, dz);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }
@@ -464,4 +498,19 @@ extern "C" int p2r_stgcn_tconv_weight_grad(int N, int T, int V, int taps, const 
                : tconv_dw_launch<1, 53>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
   return taps == 3 ? tconv_dw_launch<3, 0>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream)
                    : tconv_dw_launch<1, 0>(N, T, V, x, scale, shift, dout, n_blocks, dw_partial, dbias_partial, stream);
+}
+
+// The weight gradient of the (3,1) temporal convolution of the 53-joint skeleton with the BatchNorm-backward apply
+// pass of its INPUT riding on the tile staging (stgcn_layers.py:399-412, the `tcn` Sequential: BatchNorm2d, ReLU,
+// Conv2d): besides dw_partial / dbias_partial as above,
+//   dz = scale * ((x * scale + shift > 0 ? dh : 0) - m1 - (x - mean) * invstd * m2)
+// with fin [4][64] = mean, invstd, scale, shift (p2r_bn_finalize) and m12 [2][64] = m1, m2 (rows 2, 3 of
+// p2r_bn_bwd_finalize; zeros in evaluation mode): p2r_bn_bwd_apply's mask form 2.  P2R_EINVAL for other shapes.
+extern "C" int p2r_stgcn_tconv_weight_grad_dz(int N, int T, int V, int taps, const float *x, const float *fin,
+                                              const float *dout, const float *dh, const float *m12, float *dz,
+                                              int n_blocks, float *dw_partial, float *dbias_partial, void *stream) {
+  if (N < 0 || T <= 0 || V != 53 || taps != 3 || n_blocks < 1 || !fin || !dh || !m12 || !dz) return P2R_EINVAL;
+  if (N == 0) return P2R_OK;
+  return tconv_dw_launch<3, 53, TW_F, true>(N, T, V, x, fin + 128, fin + 192, dout, n_blocks, dw_partial, dbias_partial,
+                                            stream, dh, fin, m12, dz);
 }

@@ -20,6 +20,7 @@ from .. import _lib
 from . import bn_op
 
 _N_BLOCKS = 256
+FUSE_DZ = True       # BatchNorm-backward apply inside the weight-gradient launch (53 joints, 3 taps); tests switch it off
 USE_GEN3 = True      # statically scheduled kernel (csrc/stgcn_tconv3.hip); tests switch it off to reach tconv2
 
 
@@ -150,26 +151,33 @@ class _BNReLUTConv(Function):
                                                  _lib.ptr(part), st), "bn_bwd_reduce")
             if ctx.train:
                 tot = bn_op.bwd_finalize(part, N * L)              # (dbeta, dgamma, m1, m2)
-                dbeta, dgamma, m1, m2 = tot[0], tot[1], tot[2], tot[3]
+                dbeta, dgamma, m1, m2, m12 = tot[0], tot[1], tot[2], tot[3], tot[2:]
             else:   # eval: statistics are constants, dz = scale * g
-                m1 = torch.zeros(C, device=dev)
-                m2 = torch.zeros(C, device=dev)
+                m12 = torch.zeros((2, C), device=dev)
+                m1, m2 = m12[0], m12[1]
                 if need_sums:
                     # affine gradients as nn.BatchNorm2d gives them in eval mode: with mean / invstd = the running
                     # statistics the same reduction yields (sum g, sum g * xhat) = (dbeta, dgamma)
                     tot = bn_op.bwd_finalize(part, N * L)
                     dbeta, dgamma = tot[0], tot[1]
             dz = torch.empty_like(z)
-            _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
-                                            _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
-                                            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
-                       "bn_bwd_apply")
             taps = ctx.taps
             part = torch.empty((_N_BLOCKS, 64, 64, taps), dtype=torch.float32, device=dev)
             bpart = torch.empty((_N_BLOCKS, 64), dtype=torch.float32, device=dev) if ctx.has_bias else None
-            _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale), _lib.ptr(shift),
-                                                       _lib.ptr(du), _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), st),
-                       "stgcn_tconv_weight_grad")
+            if FUSE_DZ and taps == 3 and V == 53:
+                # the BatchNorm-backward apply pass rides on the weight-gradient kernel's tile staging (it holds z)
+                _lib.check(lib.p2r_stgcn_tconv_weight_grad_dz(N, T, V, taps, _lib.ptr(z), _lib.ptr(fin), _lib.ptr(du),
+                                                              _lib.ptr(dh), _lib.ptr(m12), _lib.ptr(dz), _N_BLOCKS,
+                                                              _lib.ptr(part), _lib.ptr(bpart), st),
+                           "stgcn_tconv_weight_grad_dz")
+            else:
+                _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dh), None, _lib.ptr(z), _lib.ptr(mean),
+                                                _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(m1), _lib.ptr(m2), 2,
+                                                _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dz), None, st),
+                           "bn_bwd_apply")
+                _lib.check(lib.p2r_stgcn_tconv_weight_grad(N, T, V, taps, _lib.ptr(z), _lib.ptr(scale),
+                                                           _lib.ptr(shift), _lib.ptr(du), _N_BLOCKS, _lib.ptr(part),
+                                                           _lib.ptr(bpart), st), "stgcn_tconv_weight_grad")
             dW = _lib.sum_leading(part).view(ctx.wshape)      # the kernel writes its partials in the weight's own (c, ci, tap) order
             if ctx.has_bias:        # row sums of du ride on the weight-gradient pass
                 dbias = _lib.sum_leading(bpart)

@@ -67,6 +67,38 @@ def test_bn_relu_tconv(dev, N, T, V, train):
         close(bn_new.running_var, bn_ref.running_var, "running_var", 1e-5)
 
 
+@pytest.mark.parametrize("N,T", [(2, 40), (1, 1), (3, 9), (2, 130), (3, 64), (5, 1000)])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_bn_backward_apply_equals_the_separate_pass(dev, N, T, train):
+    """p2r_stgcn_tconv_weight_grad_dz (BatchNorm-backward apply inside the weight-gradient launch) against
+    p2r_bn_bwd_apply + p2r_stgcn_tconv_weight_grad: same arithmetic per element, fp32 contraction aside."""
+    from pose2room_amd.p2rnet import tconv_op
+    torch.manual_seed(N * 7 + T)
+    bn = torch.nn.BatchNorm2d(64).to(dev)
+    conv = torch.nn.Conv2d(64, 64, (3, 1), (1, 1), (1, 0)).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 2.0)
+    bn.train(train)
+    z = torch.randn(N, 64, T, 53, device=dev) * 1.5 + 0.3
+    go = torch.randn(N, 64, T, 53, device=dev)
+    res = {}
+    for fused in (True, False):
+        tconv_op.FUSE_DZ = fused
+        try:
+            b, c = copy.deepcopy(bn), copy.deepcopy(conv)
+            zn = z.clone().requires_grad_(True)
+            tconv_op.bn_relu_tconv(zn, b, c).backward(go)
+            res[fused] = (zn.grad, c.weight.grad, c.bias.grad, b.weight.grad, b.bias.grad)
+        finally:
+            tconv_op.FUSE_DZ = True
+    for a, b_, what in zip(res[True], res[False], ("dz", "dW", "dbias", "dgamma", "dbeta")):
+        assert torch.isfinite(a).all()
+        err = (a - b_).abs().max().item()
+        assert err <= 2e-6 * (b_.abs().max().item() + 1e-12), f"{what}: {err:.3e}"
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])   # the product itself is the same launch
+
+
 @pytest.mark.parametrize("N,T,V", [(2, 40, 53), (1, 1, 20), (3, 9, 20), (2, 130, 53), (2, 17, 64), (2, 48, 53), (3, 160, 53)])
 @pytest.mark.parametrize("train", [True, False])
 def test_bn_relu_pointwise(dev, N, T, V, train):
