@@ -40,29 +40,30 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
   constexpr int HALO = (TAPS - 1) / 2;
   constexpr int NCH = TAPS == 1 ? TC_NPO / 64 : 8;   // 64-column chunks per tile row (tile + halo <= 64 * NCH)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
   const size_t row_stride = (size_t)T * V;
+  const int rs = (int)row_stride;        // T * V < 2^29 (checked by the launcher)
   const int total_tiles = n_seq * tiles_per_seq;
 
-  float pre[8][NCH];               // this lane's share of a tile: 8 rows (wave, wave+8, ..) x NCH chunks
-  auto issue_loads = [&](int tile) {
+  // this lane's share of a tile: 8 rows (wave, wave+8, ..) x NCH chunks, each ONE buffer load through a descriptor of
+  // the row (columns outside the tile or the tensor come back as zero from the hardware range check: no predicate,
+  // clamp or exec-masked branch in the load path, see tconv_dw_kernel)
+  float pre[8][NCH];
+  auto issue_loads = [&](int tile) __attribute__((always_inline)) {
     const int seq = tile / tiles_per_seq;
     const int t0 = (tile % tiles_per_seq) * F;
     const int frames = min(F, T - t0);
-    const int in_cols = (frames + 2 * HALO) * V;
-    const long long col0 = (long long)(t0 - HALO) * V;
+    const int col0 = (t0 - HALO) * V;
+    const int bytes = 4 * min(rs, col0 + (frames + 2 * HALO) * V);
     const float *xg = x + (size_t)seq * TC_C * row_stride;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      const float *src = xg + (size_t)(wave + 8 * h) * row_stride;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(xg + (size_t)(wave + 8 * h) * row_stride), 0, bytes, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int q = lane + 64 * i;
-        const long long gc = col0 + q;
-        const bool in = q < in_cols && gc >= 0 && gc < (long long)row_stride;
-        pre[h][i] = in ? src[in ? gc : 0] : __int_as_float(0x7fc00000);   // NaN marks "outside": stays zero
-      }
+      for (int i = 0; i < NCH; ++i)
+        pre[h][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, 4 * lane + 4 * (col0 + 64 * i), 0, 0));
     }
   };
 
@@ -79,6 +80,12 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
     float *og = out + (size_t)seq * TC_C * row_stride + (size_t)t0 * V;
 
     // registers -> LDS with the BatchNorm affine + ReLU applied on the way
+    bool in[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = lane + 64 * i, gc = (t0 - HALO) * V + q;
+      in[i] = q < (frames + 2 * HALO) * V && gc >= 0 && gc < rs;
+    }
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       const int c = wave + 8 * h;
@@ -87,8 +94,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
       for (int i = 0; i < NCH; ++i) {
         const int q = lane + 64 * i;
         float v = pre[h][i];
-        if (v != v) v = 0.f;                                   // outside the sequence / tile
-        else if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        v = in[i] ? v : 0.f;                                   // outside the sequence / tile
         if (q < row_len) hs[c * row_len + q] = v;
       }
     }
@@ -433,6 +440,7 @@ static int tconv_forward_launch(int N, int T, int V, const float *x, const float
   if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
   const size_t lds = (size_t)TC_C * row_len * sizeof(float) + 2 * TC_C * sizeof(float);
   if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
+  if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   {
     hipError_t e = p2r_allow_big_lds(tconv_fused_kernel<TAPS>, lds_ok);
