@@ -153,38 +153,44 @@ def test_fused_block_chain_matches_module_chain(dev):
 def test_lazy_residual_gradient_is_the_masked_one(dev):
     """The residual-branch gradient of an st_gcn_block is handed to the graph-conv data gradient unmasked (+ the ReLU mask
     bytes, bn_op.ResLink) and multiplied there: the same additions of the same values as when the BatchNorm-backward pass
-    writes dout * mask.  Two runs of this backbone are not bit-identical even with the switch in the same position (the
-    position embedding's first-generation kernels merge their statistics with LDS float atomics, and six train-mode
-    BatchNorm blocks amplify the last-bit differences), so the comparison is against that run-to-run spread: switching the
-    hand-over must not move any gradient by more than a few times what repeating the same run moves it (a mis-applied
-    mask would be O(1) of the gradient)."""
+    writes dout * mask.  The six blocks are fed a fixed activation (the embedding in front of them merges its statistics
+    with LDS float atomics: two runs of the whole backbone differ by a flipped borderline ReLU now and then, 5e-3 of a
+    gradient), so that the forward pass of both runs is the same bit for bit and the two hand-overs can be held to
+    rounding: a mis-applied mask would be O(1) of the gradient."""
     import copy
+    from pose2room_amd.p2rnet.gcn_op import prepare_chain
     from pose2room_amd.p2rnet.modules.stgcn_layers import st_gcn_block
-    from pose2room_amd.p2rnet.synthetic import make_batch
     net, cfg = build('train', 64, device=dev)
-    net = net.to(dev).train()
-    joints = make_batch(2, 64, seed=5, device=dev)['input_joints']
-    go = torch.randn(2, 512, 256, generator=torch.Generator().manual_seed(1)).to(dev)
+    bb = net.to(dev).train().backbone
+    x0 = torch.randn(2, 64, 64, 53, generator=torch.Generator().manual_seed(5)).to(dev)
+    go = torch.randn(2, 64, 64, 53, generator=torch.Generator().manual_seed(1)).to(dev)
 
     def run(lazy):
-        model = copy.deepcopy(net)
+        model = copy.deepcopy(bb)
         st_gcn_block.lazy_residual_grad = lazy
         try:
-            sf = model.backbone(joints, {})['seed_features']
-            sf.backward(go)
+            blocks = model.st_gcn_networks
+            tables = blocks[0].gcn.tables
+            x = x0.clone().requires_grad_(True)
+            h = x
+            assert tables is not None and tables.gen2 and all(b.chainable(h, model.A) for b in blocks)
+            for gcn, prep in zip(blocks, prepare_chain(blocks, model.A, model.edge_importance, tables)):
+                h, _ = gcn(h, prep.Aeff, prepared=prep)
+            h.backward(go)
         finally:
             st_gcn_block.lazy_residual_grad = True
-        return {k: p.grad.clone() for k, p in model.backbone.named_parameters() if p.grad is not None}
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        grads['x'] = x.grad.clone()
+        return h.detach(), grads
 
-    a1, a2, b = run(True), run(True), run(False)
-    assert set(a1) == set(b) and len(b) > 60
-    worst_noise = worst_switch = 0.0
+    (ha, a), (hb, b) = run(True), run(False)
+    assert torch.equal(ha, hb)
+    assert set(a) == set(b) and len(b) > 50
+    worst = 0.0
     for k in b:
         scale = b[k].abs().max().item()
-        if k.endswith('gcn.conv.bias') or k.endswith('tcn.2.bias') or (k.endswith('conv.bias') and 'embed' in k) or scale < 1e-8:
+        if k.endswith('gcn.conv.bias') or k.endswith('tcn.2.bias') or scale < 1e-8:
             continue        # zero in exact arithmetic (bias in front of a train-mode BatchNorm): rounding noise
-        worst_noise = max(worst_noise, (a1[k] - a2[k]).abs().max().item() / scale)
-        worst_switch = max(worst_switch, (a1[k] - b[k]).abs().max().item() / scale)
-    print('run-to-run', worst_noise, 'lazy vs written residual gradient', worst_switch)
-    assert worst_switch <= 5 * worst_noise + 1e-5, (worst_switch, worst_noise)
-    assert worst_switch < 5e-2
+        worst = max(worst, (a[k] - b[k]).abs().max().item() / scale)
+    print('lazy vs written residual gradient', worst)
+    assert worst <= 2e-6, worst
