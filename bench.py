@@ -135,6 +135,8 @@ _TIMED = {
     'p2r_stgcn_tconv3_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
     'p2r_stgcn_tconv2_forward': lambda a: None if (_null(a[9]) or a[3] != 3) else ('tconv_data_gradient' if _null(a[5]) else 'tconv_forward'),
     'p2r_stgcn_tconv_weight_grad': lambda a: 'tconv_weight_grad' if a[3] == 3 else None,
+    # the same launch with the BatchNorm-backward apply pass of the input BatchNorm riding on it (+0.9 GB of HBM traffic)
+    'p2r_stgcn_tconv_weight_grad_dz': lambda a: 'tconv_weight_grad' if a[3] == 3 else None,
     # vote / proposal heads on the job-list kernels (csrc/pw_layers.hip): in-step time only
     'p2r_pw_gemm': lambda a: 'heads_pw_gemm',
     'p2r_pw_wgrad': lambda a: 'heads_pw_wgrad',
