@@ -65,6 +65,27 @@ __global__ __launch_bounds__(256) void gather_frames_grad_kernel(int C, int T, i
     if (t0 + f >= T) continue;
     const int cnt = nhit[f];
     float *xb = dx + ((size_t)b * C * T + t0) * J + e;
+    if (cnt <= 2) {        // the usual case (S <= T, seeds spread over the sequence): no inner loop, eight channels in flight
+      const float *r0 = dout + ((size_t)b * S + (cnt > 0 ? hits[f][0] : 0)) * n + j;
+      const float *r1 = dout + ((size_t)b * S + (cnt > 1 ? hits[f][1] : 0)) * n + j;
+      int c = 0;
+      for (; c + 8 <= C; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = cnt > 0 ? r0[(c + u) * J] : 0.f;
+          if (cnt > 1) v[u] += r1[(c + u) * J];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xb[(size_t)(c + u) * T * J] = v[u];
+      }
+      for (; c < C; ++c) {
+        float v = cnt > 0 ? r0[c * J] : 0.f;
+        if (cnt > 1) v += r1[c * J];
+        xb[(size_t)c * T * J] = v;
+      }
+      continue;
+    }
     for (int c = 0; c < C; ++c) {
       float acc = 0.f;
       if (cnt <= GF_MAXHIT) {
