@@ -201,14 +201,16 @@ __host__ __device__ constexpr int tw_row(int cols) {   // + room for the last (p
 //   dz = scale * ((z * scale + shift > 0 ? dh : 0) - m1 - (z - mean) * invstd * m2)       (bn_bwd_apply, mask form 2)
 // leaves from the staging pass and the separate apply pass (read dh, read z, write dz) is gone: one more read and
 // one write of the tensor in a kernel that leaves two thirds of the HBM rate unused.
-template <int TAPS, int VS, int F = TW_F, bool DZ = false>
+template <int TAPS, int VS, int F = TW_F, bool DZ = false, bool XF = true>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V_, int row_d_, int row_h_, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
     float *__restrict__ dw_partial, float *__restrict__ dbias_partial, const float *__restrict__ dh = nullptr,
     const float *__restrict__ fin = nullptr, const float *__restrict__ m12 = nullptr, float *__restrict__ dz = nullptr) {
   constexpr int HALO = (TAPS - 1) / 2;
-  constexpr int NH = TAPS == 1 ? 4 : 6;  // 64-column chunks of the h tile per row
+  // 64-column chunks of the h tile per row (the unrolled instances stage only the chunks that hold columns: the pad
+  // columns behind them are zeroed once, below, and never written again)
+  constexpr int NH = VS > 0 ? ((F + 2 * HALO) * VS + 63) / 64 : (TAPS == 1 ? 4 : 6);
   // joint count and row strides are compile-time constants in the fully unrolled instances (write predicates fold)
   const int V = VS > 0 ? VS : V_;
   const int row_d = VS > 0 ? tw_row(F * VS) : row_d_, row_h = VS > 0 ? tw_row((F + 2 * HALO) * VS) : row_h_;
@@ -297,16 +299,19 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
   for (; tile < total_tiles; tile += gridDim.x) {
     __syncthreads();                                   // previous tile fully consumed
     // ld_* still describe the tile that sits in the registers
+    // a tile inside its sequence needs no validity mask except for the tail of the last chunk (columns the loads got
+    // as zeros would otherwise become relu(shift))
+    const bool interior = VS > 0 && ld_col0 >= 0 && ld_col0 + (F + 2 * HALO) * V <= rs;     // wave-uniform
     bool hin[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int q = lane + 64 * i, gc = ld_col0 + q;
-      hin[i] = q < ld_hcols && gc >= 0 && gc < rs;
+      hin[i] = interior ? q < (F + 2 * HALO) * V : (q < ld_hcols && gc >= 0 && gc < rs);
     }
 #pragma unroll
     for (int hh = 0; hh < NR; ++hh) {
       const int c = wave + hh * (TW_THREADS / 64);
-      const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+      const float sc = XF ? scale[c] : 1.f, sh = XF ? shift[c] : 0.f;
       bsum[hh] += (pd_[hh][0] + pd_[hh][1]) + (pd_[hh][2] + pd_[hh][3]);
       if constexpr (DZ) {
         const float mu = fin[c], is = fin[64 + c], kk = sc, a1 = m12[c], a2 = m12[64 + c];
@@ -329,8 +334,8 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       for (int i = 0; i < NH; ++i) {
         const int q = lane + 64 * i;
         float v = ph_[hh][i];
-        if (scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
-        v = hin[i] ? v : 0.f;
+        if (XF) v = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (!(VS > 0 && interior && 64 * (i + 1) <= (F + 2 * HALO) * VS)) v = hin[i] ? v : 0.f;
         if (q < row_h) hs[c * row_h + q] = v;
       }
 #pragma unroll
@@ -477,13 +482,18 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
   if (lds > 160 * 1024 || F * V > 256 || (F + 2 * HALO) * V > (TAPS == 1 ? 256 : 384)) return P2R_EINVAL;
   if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
-  static unsigned char lds_ok[P2R_MAX_DEVICES];
-  {
-    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, DZ>, lds_ok);
+  static unsigned char lds_ok[2][P2R_MAX_DEVICES];
+  if (scale || DZ) {     // with the input transform relu(x * scale + shift)
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, DZ, true>, lds_ok[0]);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, DZ, true>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N,
+                       T, V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin, m12, dz);
+  } else {
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, false, false>, lds_ok[1]);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, false, false>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream),
+                       N, T, V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin, m12, dz);
   }
-  hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, DZ>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N, T,
-                     V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin, m12, dz);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

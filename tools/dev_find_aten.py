@@ -20,7 +20,7 @@ for e in prof.events():
     if not ks: continue
     if any(getattr(c, 'kernels', None) for c in e.cpu_children): continue
     for k in ks:
-        if k.duration > 15 and ('reduce_kernel' in k.name or 'elementwise' in k.name or 'copy' in k.name.lower() or 'index' in k.name):
+        if k.duration > 2 and ('at::native' in k.name or 'reduce_kernel' in k.name or 'elementwise' in k.name or 'copy' in k.name.lower() or 'index' in k.name):
             st = [f for f in (e.stack or []) if 'pose2room_amd' in f or 'bench' in f]
             p = e
             chain = []
@@ -28,5 +28,5 @@ for e in prof.events():
                 chain.append(p.name[:40]); p = p.cpu_parent
             key = (k.name[:60], (st[0].split('pose2room_amd/')[-1] if st else ' <- '.join(chain)))
             cnt[key] += 1; tim[key] += k.duration
-for key, t in tim.most_common(25):
+for key, t in tim.most_common(60):
     print(f'{t/1e3:7.3f} ms {cnt[key]:3d}  {key[0]}  @ {key[1][:110]}')
