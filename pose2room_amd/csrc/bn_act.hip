@@ -85,8 +85,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
                                                               const float *__restrict__ res,
                                                               float *__restrict__ y,
                                                               unsigned char *__restrict__ mask) {
-  const int rowi = blockIdx.x / chunks;
-  const int chunk = blockIdx.x % chunks;
+  // last rows first: the producer (temporal conv, ascending tiles) wrote them last and part of them is still on
+  // chip (-3 % in the step); the consumer that follows starts with the rows this pass writes last
+  const int bid = (int)(gridDim.x - 1 - blockIdx.x);
+  const int rowi = bid / chunks;
+  const int chunk = bid % chunks;
   const int c = rowi % C;
   const float sc = scale[c], sh = shift[c];
   const size_t base = (size_t)rowi * L;
