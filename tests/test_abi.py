@@ -96,3 +96,17 @@ def test_reserved_register_check_is_part_of_the_build():
     assert chk.named_registers(os.path.join(csrc, 'stgcn_tconv3.hip')) == set(range(224, 256))
     assert chk.named_registers(os.path.join(csrc, 'ball_query.hip')) == set()
     assert chk.offenders(os.path.join(csrc, 'ball_query.hip'), reserved={0, 1}), "the checker must see compiler-used registers"
+
+
+def test_shape_restricted_entry_points_refuse_other_shapes():
+    """Entry points that exist for one shape only return P2R_EINVAL for anything else -- before they touch the device,
+    so this runs on a CPU-only box (the callers fall back to the generic launches on that status)."""
+    l = _lib.lib()
+    EINVAL = -22
+    n = None
+    # weight gradient + BatchNorm-backward apply: 53 joints, 3 taps only; NULL operands
+    assert l.p2r_stgcn_tconv_weight_grad_dz(2, 16, 20, 3, n, n, n, n, n, n, 256, n, n, n) == EINVAL
+    assert l.p2r_stgcn_tconv_weight_grad_dz(2, 16, 53, 1, n, n, n, n, n, n, 256, n, n, n) == EINVAL
+    assert l.p2r_stgcn_tconv_weight_grad_dz(2, 16, 53, 3, n, n, n, n, n, n, 256, n, n, n) == EINVAL
+    assert l.p2r_stgcn_tconv_weight_grad(2, 16, 65, 3, n, n, n, n, 256, n, n, n) == EINVAL
+    assert l.p2r_stgcn_tconv_weight_grad(2, 16, 53, 2, n, n, n, n, 256, n, n, n) == EINVAL
