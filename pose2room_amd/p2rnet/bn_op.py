@@ -98,6 +98,18 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
     return (y, mask) if want_mask else y
 
 
+OVERLAP_APPLY = True      # BatchNorm-backward apply pass on a side stream under the graph conv's gradient kernels
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
+
 class BNLink(object):
     """Handshake between a fused BatchNorm (+res) + ReLU and the graph conv that consumes its output y.
 
@@ -108,10 +120,11 @@ class BNLink(object):
     sums belong to and `grad_version` its version counter when the kernel wrote it; the BatchNorm backward uses
     the sums only for that very buffer in that very state (a second consumer of y would make autograd hand over a
     different tensor, or accumulate into this one in place, which bumps the counter)."""
-    __slots__ = ('u', 'mask', 'fin', 'versions', 'partials', 'grad_ptr', 'grad_version', 'used')
+    __slots__ = ('u', 'mask', 'fin', 'versions', 'partials', 'grad_ptr', 'grad_version', 'used', 'ready')
 
     def __init__(self):
         self.u = self.mask = self.fin = self.versions = self.partials = self.grad_ptr = self.grad_version = None
+        self.ready = None       # event recorded right behind the kernel that wrote the gradient and `partials`
         self.used = 0           # how many backward passes took the sums from the link (tests)
 
     def attach(self, u, mask, fin):
@@ -186,20 +199,46 @@ class _FusedBNAct(Function):
                 part = link.partials        # emitted by the kernel that wrote dy (gcn_op._GraphConv.backward)
                 link.used += 1
             link.partials = link.grad_ptr = link.grad_version = None
+        ready = None
+        if link is not None:
+            ready, link.ready = link.ready, None
         if part is None:
+            ready = None
             part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
                                                  _lib.ptr(invstd), mode, None, None, _lib.ptr(part),
                                                  _lib.current_stream(dev)), "bn_bwd_reduce")
-        tot = bwd_finalize(part, N * L)                       # (dbeta, dgamma, m1, m2)
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (ctx.has_res and ctx.lazy_res is None) else None
-        with torch.cuda.device(dev):
-            _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
-                                            _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot[2]), _lib.ptr(tot[3]),
-                                            mode, None, None, _lib.ptr(dx), _lib.ptr(dres),
-                                            _lib.current_stream(dev)), "bn_bwd_apply")
+
+        def apply_pass():
+            tot_ = bwd_finalize(part, N * L)                  # (dbeta, dgamma, m1, m2)
+            dx_ = torch.empty_like(x)
+            dres_ = torch.empty_like(x) if (ctx.has_res and ctx.lazy_res is None) else None
+            with torch.cuda.device(dev):
+                _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
+                                                _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot_[2]), _lib.ptr(tot_[3]),
+                                                mode, None, None, _lib.ptr(dx_), _lib.ptr(dres_),
+                                                _lib.current_stream(dev)), "bn_bwd_apply")
+            return tot_, dx_, dres_
+
+        if OVERLAP_APPLY and ready is not None:
+            # dy and the sums were complete at `ready` (recorded right behind the graph conv's data-gradient launch), but
+            # this stream still has that op's weight- and adjacency-gradient kernels queued in front of us: ~2 ms of
+            # MFMA-bound work that nothing here depends on and that leaves 100+ VGPRs per SIMD and two thirds of the
+            # HBM rate unused.  The finalisation and the streaming apply pass go to a side stream that waits for
+            # `ready` only and run UNDER those kernels; this stream joins before anything reads the results.
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                tot, dx, dres = apply_pass()
+                done = torch.cuda.Event()
+                done.record(side)
+            main.wait_event(done)
+            for t_ in (tot, dx, dres):
+                if t_ is not None:
+                    t_.record_stream(main)                    # allocated from the side stream's pool, consumed here
+        else:
+            tot, dx, dres = apply_pass()
         if ctx.lazy_res is not None:
             ctx.lazy_res.mask, ctx.lazy_res.grad_ptr, ctx.lazy_res.grad_version = mask, dy.data_ptr(), dy._version
             dres = dy

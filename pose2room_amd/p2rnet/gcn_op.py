@@ -216,6 +216,10 @@ class _GraphConv(Function):
                     # two per-channel sums from here instead of a pass over dx and its saved input
                     dx, link.partials = dx
                     link.grad_ptr, link.grad_version = dx.data_ptr(), dx._version
+                    # dx and the sums are complete HERE; the weight- and adjacency-gradient launches below do not
+                    # touch them (bn_op._FusedBNAct.backward runs its apply pass under them, on a side stream)
+                    link.ready = torch.cuda.Event()
+                    link.ready.record(torch.cuda.current_stream(dev))
                 dres = None
             else:
                 if dres_mask is not None:
