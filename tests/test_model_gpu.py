@@ -150,6 +150,47 @@ def test_fused_block_chain_matches_module_chain(dev):
     close(blk.tcn[3].running_var, ref.tcn[3].running_var, 'running_var', 1e-5)
 
 
+def test_side_stream_bn_backward_apply_is_the_same_pass(dev):
+    """bn_op.OVERLAP_APPLY runs the BatchNorm-backward apply pass of a block's output BatchNorm on a side stream, under the
+    next block's weight- and adjacency-gradient kernels; the same launches on the same operands, so every gradient of the
+    block chain must come out bit for bit as with everything on one stream (a missed dependency would not)."""
+    import copy
+    from pose2room_amd.p2rnet import bn_op
+    from pose2room_amd.p2rnet.gcn_op import prepare_chain
+    net, cfg = build('train', 64, device=dev)
+    bb = net.to(dev).train().backbone
+    x0 = torch.randn(4, 64, 64, 53, generator=torch.Generator().manual_seed(7)).to(dev)
+    go = torch.randn(4, 64, 64, 53, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(overlap):
+        model = copy.deepcopy(bb)
+        bn_op.OVERLAP_APPLY = overlap
+        used = []
+        try:
+            blocks = model.st_gcn_networks
+            tables = blocks[0].gcn.tables
+            x = x0.clone().requires_grad_(True)
+            h = x
+            for gcn, prep in zip(blocks, prepare_chain(blocks, model.A, model.edge_importance, tables)):
+                h, _ = gcn(h, prep.Aeff, prepared=prep)
+            for _ in range(3):                       # a few passes: a race would not show every time
+                for p in model.parameters():
+                    p.grad = None
+                x.grad = None
+                h.backward(go, retain_graph=True)
+                torch.cuda.synchronize()
+                used.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None} | {'x': x.grad.clone()})
+        finally:
+            bn_op.OVERLAP_APPLY = True
+        return used
+
+    a, b = run(True), run(False)
+    assert len(b[0]) > 50
+    for ga in a:
+        for k in b[0]:
+            assert torch.equal(ga[k], b[0][k]), k
+
+
 def test_lazy_residual_gradient_is_the_masked_one(dev):
     """The residual-branch gradient of an st_gcn_block is handed to the graph-conv data gradient unmasked (+ the ReLU mask
     bytes, bn_op.ResLink) and multiplied there: the same additions of the same values as when the BatchNorm-backward pass
