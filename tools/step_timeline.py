@@ -76,10 +76,20 @@ def main():
     lo, hi = cuts[k], cuts[k + 1]
     step = rows[lo:hi]
     span = step[-1][1] - step[0][0]
-    busy = sum(e - s for s, e, _ in step)
-    gaps = [max(step[i][0] - step[i - 1][1], 0) for i in range(1, len(step))]
+    # kernels of two streams may overlap (the BatchNorm-backward apply pass on its side stream): the device is busy over
+    # the UNION of the intervals, the gaps are what the union leaves of the span
+    total = sum(e - s for s, e, _ in step)
+    gaps, cover_end, busy = [], step[0][0], 0
+    for s_, e_, _ in sorted((s, e, n) for s, e, n in step):
+        if s_ > cover_end:
+            gaps.append(s_ - cover_end)
+            busy += e_ - s_
+        elif e_ > cover_end:
+            busy += e_ - cover_end
+        cover_end = max(cover_end, e_)
     print(f'step {k}: {len(step)} launches, span {span / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, '
-          f'idle {sum(gaps) / 1e6:.3f} ms (gaps > 20 us: {sum(1 for g in gaps if g > 20000)})')
+          f'idle {sum(gaps) / 1e6:.3f} ms (gaps > 20 us: {sum(1 for g in gaps if g > 20000)})'
+          + (f', kernel time {total / 1e6:.3f} ms ({(total - busy) / 1e6:.3f} ms of it overlapped)' if total - busy > 1000 else ''))
     cnt, tim = collections.Counter(), collections.Counter()
     fam_c, fam_t = collections.Counter(), collections.Counter()
     for s, e, n in step:
