@@ -237,6 +237,19 @@ int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int form, const
                            float *stats_partial, int *n_partials, const float *bwd_u,
                            const unsigned char *bwd_mask, const float *bwd_fin, void *stream_h);
 
+/* The data-gradient launch of p2r_stgcn_gcn3_forward (form = 1, no bias table) whose addend is MASKED on the way in:
+ * z += addend where addend_mask (N,64,T,53 bytes, 4-byte aligned) is non-zero.  In the backward of a chain of
+ * st_gcn blocks (stgcn_layers.py:413-439: `x = self.tcn(x) + res; return self.relu(x), A`) addend = the gradient
+ * arriving at the previous block's output and addend_mask = that block's ReLU mask: the residual-branch gradient
+ * dout * mask, which the BatchNorm-backward pass then does not have to write.  bwd_u / bwd_mask / bwd_fin and
+ * stats_partial as in p2r_stgcn_gcn3_forward: all given = with the BatchNorm-backward sums epilogue, all NULL = plain
+ * (the caller runs p2r_bn_bwd_reduce itself, e.g. on another stream under the gradient kernels that follow). */
+int p2r_stgcn_gcn3_data_gradient_masked_addend(int N, int T, int V, int K, int ltot, const float *x,
+                                               const float *Wp, const float *coef, const float *addend,
+                                               const unsigned char *addend_mask, float *z, float *stats_partial,
+                                               const float *bwd_u, const unsigned char *bwd_mask,
+                                               const float *bwd_fin, void *stream_h);
+
 /* Adjacency gradient at the row-list entries, statically scheduled like p2r_stgcn_gcn3_forward
  * (csrc/stgcn_gcn3_grad.hip; requires p2r_stgcn_gcn3_signature(1) == signature of the caller's row tables):
  *   dcoef[lofs_k + j][v] = sum over (n, t, c) of (W_k . x)[c, t, v] * dz[c, t, w_j(k, v)]

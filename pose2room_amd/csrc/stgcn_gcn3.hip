@@ -255,7 +255,7 @@ __device__ __forceinline__ void g3_wave_main(
     const float *ag = addend ? addend + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const float *ug = BWD ? bwd_u + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const unsigned char *mg = BWD ? bwd_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
-    const unsigned char *amg = (BWD && MADD) ? addend_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
+    const unsigned char *amg = MADD ? addend_mask + (size_t)seq * 64 * row_stride + (size_t)t0 * V : nullptr;
     const int ntile = tile + gridDim.x;
     const bool has_next = ntile < p.total_tiles;
     const int nseq = has_next ? ntile / p.tiles_per_seq : 0, nt0 = has_next ? (ntile % p.tiles_per_seq) * G3_F : 0;
@@ -350,26 +350,32 @@ __device__ __forceinline__ void g3_wave_main(
       // BWD: saved activation, mask bytes and addend of the two rows this wave stores in a round.  A row's buffers are
       // reloaded for the next round as soon as the row has been processed (see stgcn_tconv3.hip): the loads then have
       // the rest of the round, its closing barrier and the next staging to arrive.
+      // ROWS: the row-per-wave store form with its operands fetched a round ahead -- the BatchNorm-backward launches, and
+      // the plain launch with a masked addend (as a straight load-add-store loop its 0.55 GB of addend + mask reads
+      // cost as much as the whole sums epilogue)
+      constexpr bool ROWS = BWD || MADD;
       float4 uv[BWD ? 2 : 1][BWD ? RIT : 1];
-      float4 ad[BWD ? 2 : 1][BWD ? RIT : 1];
+      float4 ad[ROWS ? 2 : 1][ROWS ? RIT : 1];
       unsigned mk[BWD ? 2 : 1][BWD ? RIT : 1];
-      unsigned mk2[(BWD && MADD) ? 2 : 1][(BWD && MADD) ? RIT : 1];
+      unsigned mk2[MADD ? 2 : 1][MADD ? RIT : 1];
       auto load_bwd = [&](int m, int rr) {
         const size_t r0 = (size_t)(16 * m + 2 * wave + rr) * row_stride;
-        const float4 *u4 = reinterpret_cast<const float4 *>(ug + r0);
-        const unsigned *m4 = reinterpret_cast<const unsigned *>(mg + r0);
+        const float4 *u4 = reinterpret_cast<const float4 *>(BWD ? ug + r0 : nullptr);
+        const unsigned *m4 = reinterpret_cast<const unsigned *>(BWD ? mg + r0 : nullptr);
         const float4 *a4 = reinterpret_cast<const float4 *>(ag ? ag + r0 : nullptr);
-        const unsigned *am4 = reinterpret_cast<const unsigned *>((BWD && MADD) ? amg + r0 : nullptr);
+        const unsigned *am4 = reinterpret_cast<const unsigned *>(MADD ? amg + r0 : nullptr);
 #pragma unroll
-        for (int it = 0; it < (BWD ? RIT : 1); ++it) {
+        for (int it = 0; it < (ROWS ? RIT : 1); ++it) {
           const int c4 = it * 64 + lane;
-          uv[BWD ? rr : 0][it] = c4 < R4 ? u4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-          mk[BWD ? rr : 0][it] = c4 < R4 ? m4[c4] : 0u;
-          if (a4 && c4 < R4) ad[BWD ? rr : 0][it] = a4[c4];
-          if (BWD && MADD) mk2[(BWD && MADD) ? rr : 0][it] = c4 < R4 ? am4[c4] : 0u;
+          if (BWD) {
+            uv[BWD ? rr : 0][it] = c4 < R4 ? u4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            mk[BWD ? rr : 0][it] = c4 < R4 ? m4[c4] : 0u;
+          }
+          if (a4 && c4 < R4) ad[ROWS ? rr : 0][it] = a4[c4];
+          if (MADD) mk2[MADD ? rr : 0][it] = c4 < R4 ? am4[c4] : 0u;
         }
       };
-      if (BWD) { load_bwd(0, 0); load_bwd(0, 1); }
+      if (ROWS) { load_bwd(0, 0); load_bwd(0, 1); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -386,11 +392,11 @@ __device__ __forceinline__ void g3_wave_main(
         float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
         const float4 *arow = reinterpret_cast<const float4 *>(ag ? ag + (size_t)16 * m * row_stride : nullptr);
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
-        if (BWD) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
+        if (ROWS) {   // a wave takes two whole rows: the per-channel sums stay in registers until the row is done
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             const int row = 2 * wave + rr, c = 16 * m + row;
-            const float mu = bstat[2 * c], is = bstat[2 * c + 1];
+            const float mu = BWD ? bstat[2 * c] : 0.f, is = BWD ? bstat[2 * c + 1] : 0.f;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int it = 0; it < RIT; ++it) {
@@ -398,8 +404,8 @@ __device__ __forceinline__ void g3_wave_main(
               if (c4 < R4) {
                 float4 v = srow[row * R4 + c4];
                 if (arow) {
-                  if (BWD && MADD) {
-                    const unsigned m2 = mk2[(BWD && MADD) ? rr : 0][it];
+                  if (MADD) {
+                    const unsigned m2 = mk2[MADD ? rr : 0][it];
                     v.x += (m2 & 0xffu) ? ad[rr][it].x : 0.f; v.y += (m2 & 0xff00u) ? ad[rr][it].y : 0.f;
                     v.z += (m2 & 0xff0000u) ? ad[rr][it].z : 0.f; v.w += (m2 & 0xff000000u) ? ad[rr][it].w : 0.f;
                   } else {
@@ -407,23 +413,27 @@ __device__ __forceinline__ void g3_wave_main(
                   }
                 }
                 zrow[(size_t)row * (row_stride / 4) + c4] = v;
-                const float4 uu = uv[rr][it];
-                const unsigned mm = mk[rr][it];
-                const float g0 = (mm & 0xffu) ? v.x : 0.f, g1 = (mm & 0xff00u) ? v.y : 0.f;
-                const float g2 = (mm & 0xff0000u) ? v.z : 0.f, g3 = (mm & 0xff000000u) ? v.w : 0.f;
-                s1 += (g0 + g1) + (g2 + g3);
-                s2 = fmaf(g0, (uu.x - mu) * is, s2); s2 = fmaf(g1, (uu.y - mu) * is, s2);
-                s2 = fmaf(g2, (uu.z - mu) * is, s2); s2 = fmaf(g3, (uu.w - mu) * is, s2);
+                if (BWD) {
+                  const float4 uu = uv[BWD ? rr : 0][it];
+                  const unsigned mm = mk[BWD ? rr : 0][it];
+                  const float g0 = (mm & 0xffu) ? v.x : 0.f, g1 = (mm & 0xff00u) ? v.y : 0.f;
+                  const float g2 = (mm & 0xff0000u) ? v.z : 0.f, g3 = (mm & 0xff000000u) ? v.w : 0.f;
+                  s1 += (g0 + g1) + (g2 + g3);
+                  s2 = fmaf(g0, (uu.x - mu) * is, s2); s2 = fmaf(g1, (uu.y - mu) * is, s2);
+                  s2 = fmaf(g2, (uu.z - mu) * is, s2); s2 = fmaf(g3, (uu.w - mu) * is, s2);
+                }
               }
             }
+            if (BWD) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-              s1 += __shfl_xor(s1, off, 64);
-              s2 += __shfl_xor(s2, off, 64);
-            }
-            if (lane == 0) {
-              rs[G3_ST * c] += s1;
-              rs[G3_ST * c + 1] += s2;
+              for (int off = 32; off >= 1; off >>= 1) {
+                s1 += __shfl_xor(s1, off, 64);
+                s2 += __shfl_xor(s2, off, 64);
+              }
+              if (lane == 0) {
+                rs[G3_ST * c] += s1;
+                rs[G3_ST * c + 1] += s2;
+              }
             }
             if (m + 1 < 4) load_bwd(m + 1, rr);
           }
@@ -576,10 +586,13 @@ static int gcn3_forward_impl(int N, int T, int V, int K, int ltot, int form, con
     return gcn3_launch<0, false>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, nullptr, nullptr,
                                  nullptr, stream_h);
   }
-  if (addend_mask) {     // addend masked on the way in: only with the BatchNorm-backward epilogue (the ST-GCN chain)
-    if (!bwd || !addend || ((uintptr_t)addend_mask % 4) != 0) return P2R_EINVAL;
-    return gcn3_launch<1, true, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, bwd_u, bwd_mask,
-                                      bwd_fin, stream_h, addend_mask);
+  if (addend_mask) {     // addend masked on the way in (the ST-GCN chain), with or without the BatchNorm-backward epilogue
+    if (!addend || ((uintptr_t)addend_mask % 4) != 0) return P2R_EINVAL;
+    if (bwd)
+      return gcn3_launch<1, true, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, bwd_u,
+                                        bwd_mask, bwd_fin, stream_h, addend_mask);
+    return gcn3_launch<1, false, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, nullptr, nullptr,
+                                       nullptr, stream_h, addend_mask);
   }
   if (bwd) return gcn3_launch<1, true>(p, ltot, blocks, lds, x, Wp, coef, bias_cv, addend, z, stats_partial, bwd_u, bwd_mask,
                                        bwd_fin, stream_h);
@@ -595,8 +608,8 @@ extern "C" int p2r_stgcn_gcn3_forward(int N, int T, int V, int K, int ltot, int 
                            bwd_fin, nullptr, stream_h);
 }
 
-// The data-gradient launch with the BatchNorm-backward epilogue (form 1, bwd_* given) whose addend is MASKED on the way
-// in: z += addend where addend_mask (N,64,T,53 bytes) is non-zero.  With addend = the gradient arriving at a block's
+// The data-gradient launch (form 1; with the BatchNorm-backward epilogue when bwd_* are given, plain when they and
+// stats_partial are NULL) whose addend is MASKED on the way in: z += addend where addend_mask (N,64,T,53 bytes) is non-zero.  With addend = the gradient arriving at a block's
 // output and addend_mask = that block's ReLU mask this is the residual-branch gradient dout * mask, which the
 // BatchNorm-backward pass then does not have to write.  addend_mask 4-byte aligned.
 extern "C" int p2r_stgcn_gcn3_data_gradient_masked_addend(int N, int T, int V, int K, int ltot, const float *x,

@@ -99,6 +99,7 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
 
 
 OVERLAP_APPLY = True      # BatchNorm-backward apply pass on a side stream under the graph conv's gradient kernels
+OVERLAP_REDUCE = True     # ... and its reduction pass too (the data-gradient kernel then runs without the sums epilogue)
 _SIDE = {}
 
 
@@ -192,26 +193,32 @@ class _FusedBNAct(Function):
         N, C, L = _rows(x)
         dev = x.device
         lib = _lib.lib()
-        link, part = ctx.link, None
+        link, part, ready = ctx.link, None, None
         if link is not None:
-            if (link.partials is not None and link.grad_ptr == dy.data_ptr()
-                    and link.grad_version == dy._version):
-                part = link.partials        # emitted by the kernel that wrote dy (gcn_op._GraphConv.backward)
+            if link.grad_ptr == dy.data_ptr() and link.grad_version == dy._version and (
+                    link.partials is not None or link.ready is not None):
+                # dy is the buffer the graph conv's data-gradient kernel wrote (gcn_op._GraphConv.backward), in the state
+                # it left it in: `partials` = the two sums from that kernel's epilogue (or None: reduce here, see below),
+                # `ready` = the event recorded right behind that launch
+                part, ready = link.partials, link.ready
                 link.used += 1
-            link.partials = link.grad_ptr = link.grad_version = None
-        ready = None
-        if link is not None:
-            ready, link.ready = link.ready, None
-        if part is None:
-            ready = None
-            part = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
+            link.partials = link.grad_ptr = link.grad_version = link.ready = None
+        side_ok = OVERLAP_APPLY and ready is not None
+
+        def reduce_pass():
+            part_ = torch.empty((N, C, 2), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.p2r_bn_bwd_reduce(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
-                                                 _lib.ptr(invstd), mode, None, None, _lib.ptr(part),
+                                                 _lib.ptr(invstd), mode, None, None, _lib.ptr(part_),
                                                  _lib.current_stream(dev)), "bn_bwd_reduce")
+            return part_
+
+        if part is None and not side_ok:
+            part = reduce_pass()
 
         def apply_pass():
-            tot_ = bwd_finalize(part, N * L)                  # (dbeta, dgamma, m1, m2)
+            part_ = part if part is not None else reduce_pass()
+            tot_ = bwd_finalize(part_, N * L)                 # (dbeta, dgamma, m1, m2)
             dx_ = torch.empty_like(x)
             dres_ = torch.empty_like(x) if (ctx.has_res and ctx.lazy_res is None) else None
             with torch.cuda.device(dev):
@@ -221,7 +228,7 @@ class _FusedBNAct(Function):
                                                 _lib.current_stream(dev)), "bn_bwd_apply")
             return tot_, dx_, dres_
 
-        if OVERLAP_APPLY and ready is not None:
+        if side_ok:
             # dy and the sums were complete at `ready` (recorded right behind the graph conv's data-gradient launch), but
             # this stream still has that op's weight- and adjacency-gradient kernels queued in front of us: ~2 ms of
             # MFMA-bound work that nothing here depends on and that leaves 100+ VGPRs per SIMD and two thirds of the

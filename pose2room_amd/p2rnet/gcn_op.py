@@ -16,7 +16,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from . import gcn_tables
+from . import bn_op, gcn_tables
 
 _N_BLOCKS = 256     # persistent workgroups of the reduction kernels (one per CU)
 
@@ -122,9 +122,9 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
     with torch.cuda.device(x.device):
         st = _lib.current_stream(x.device)
         gen3 = form is not None and _gen3_able(x, z, addend, tables, bwd)
-        if addend_mask is not None and not (gen3 and bwd is not None and form == 1 and addend_mask.data_ptr() % 4 == 0):
-            # the masked-addend form exists only in the statically scheduled data-gradient kernel with the
-            # BatchNorm-backward epilogue: anywhere else the product is formed here (one elementwise launch)
+        if addend_mask is not None and not (gen3 and form == 1 and addend_mask.data_ptr() % 4 == 0):
+            # the masked-addend form exists only in the statically scheduled data-gradient kernel: anywhere else the
+            # product is formed here (one elementwise launch)
             addend = addend * (addend_mask != 0)
             addend_mask = None
         if want_stats:      # one partial per persistent workgroup: min(tiles of 16 frames, 256); forward launches of
@@ -132,9 +132,10 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
             part = torch.empty((min(N * ((T + 15) // 16), 256), C, 3 if gen3 and bwd is None else 2),
                                dtype=torch.float32, device=x.device)
         if gen3 and addend_mask is not None:
+            bu, bm, bf = (bwd[0], bwd[1], bwd[2].contiguous()) if bwd is not None else (None, None, None)
             _lib.check(lib.p2r_stgcn_gcn3_data_gradient_masked_addend(
                 N, T, V, tables.K, ltot, _lib.ptr(x), _lib.ptr(Wp), _lib.ptr(coef), _lib.ptr(addend), _lib.ptr(addend_mask),
-                _lib.ptr(z), _lib.ptr(part), _lib.ptr(bwd[0]), _lib.ptr(bwd[1]), _lib.ptr(bwd[2].contiguous()), st),
+                _lib.ptr(z), _lib.ptr(part), _lib.ptr(bu), _lib.ptr(bm), _lib.ptr(bf), st),
                 "stgcn_gcn3_data_gradient_masked_addend")
             return (z, part) if want_stats else z
         if gen3:
@@ -206,15 +207,23 @@ class _GraphConv(Function):
             if tables.gen2:
                 link = ctx.bn_link
                 use_link = link is not None and link.intact() and link.u.shape == x.shape
+                # the sums either leave through this kernel's epilogue, or -- when the BatchNorm backward will run its
+                # passes on a side stream under the gradient kernels launched below -- are left to its own reduction pass
+                # (HBM-bound, hidden there, while the epilogue form costs 0.18 ms of this kernel with the matrix pipe idle)
+                emit = use_link and not (bn_op.OVERLAP_APPLY and bn_op.OVERLAP_REDUCE and bool(ctx.needs_input_grad[1])
+                                         and bool(ctx.needs_input_grad[3]))
                 wp_b = ctx.wp_b if ctx.wp_b is not None else permute_planes(W.view(K, C, C).transpose(1, 2))
                 dx = _gcn2_forward(dz, wp_b, coef_r.contiguous(),
                                    t['stream_r'], None, tables, addend=dres.contiguous() if dres is not None else None,
-                                   want_stats=use_link, bwd=(link.u, link.mask, link.fin) if use_link else None,
+                                   want_stats=emit, bwd=(link.u, link.mask, link.fin) if emit else None,
                                    form=1, addend_mask=dres_mask)
                 if use_link:
                     # dx is the whole gradient of the previous block's output: its BatchNorm backward takes the
                     # two per-channel sums from here instead of a pass over dx and its saved input
-                    dx, link.partials = dx
+                    if emit:
+                        dx, link.partials = dx
+                    else:
+                        link.partials = None
                     link.grad_ptr, link.grad_version = dx.data_ptr(), dx._version
                     # dx and the sums are complete HERE; the weight- and adjacency-gradient launches below do not
                     # touch them (bn_op._FusedBNAct.backward runs its apply pass under them, on a side stream)

@@ -21,6 +21,12 @@ def test_header_symbols_all_exported():
     l = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in names if not hasattr(l, n)]
     assert not missing, f"declared in include/p2r_hip.h but not exported: {missing}"
+    # ... and nothing is exported behind the header's back
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("p2r_")}
+    undeclared = sorted(exported - set(names))
+    assert not undeclared, f"exported but not declared in include/p2r_hip.h: {undeclared}"
 
 
 def test_abi_identity():
