@@ -195,6 +195,12 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
         if tag not in issued:
             ms_, n_ = per[tag]
             rows[tag] = {'ms_in_step_total': round(ms_ * n_ / steps, 4), 'launches_per_step': n_ // steps}
+    from pose2room_amd.p2rnet import bn_op
+    if bn_op.OVERLAP_APPLY:
+        for tag in ('gcn_coef_grad', 'gcn_weight_grad'):
+            if tag in rows:
+                rows[tag]['hosting'] = ('timed with the BatchNorm-backward reduce + apply passes of the block in front '
+                                        'co-resident on a side stream (5 of 6 launches); alone ~3 % faster')
     g2 = [t for t in ('gcn_forward', 'gcn_data_gradient') if t in per]
     n_g2 = sum(per[t][1] for t in g2)
     ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
