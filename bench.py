@@ -200,7 +200,8 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
         for tag in ('gcn_coef_grad', 'gcn_weight_grad'):
             if tag in rows:
                 rows[tag]['hosting'] = ('timed with the BatchNorm-backward reduce + apply passes of the block in front '
-                                        'co-resident on a side stream (5 of 6 launches); alone ~3 % faster')
+                                        'co-resident on a side stream (5 of 6 launches); without guests 0.97 ms (weight) / 1.01 ms (coefficient '
+                                        'gradient) per launch, profiles/r4q_bench_line.json')
     g2 = [t for t in ('gcn_forward', 'gcn_data_gradient') if t in per]
     n_g2 = sum(per[t][1] for t in g2)
     ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
