@@ -227,3 +227,78 @@ class PointnetFPModule(nn.Module):
         new_features = interpolated if unknow_feats is None else \
             torch.cat([interpolated, unknow_feats], dim=1)
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
+
+
+# ---- spatial-transformer grouping (pointnet2_modules.py:408-538; not instantiated by P2RNet) ----------------------------
+def weights_init(m):
+    """`module.apply` hook of the reference (pointnet2_modules.py:408-419): Conv2d and Linear layers start from zero
+    weights and biases -- so a fresh STN3d predicts the identity transform.  (Conv1d layers do not match the rule.)"""
+    kind = type(m).__name__
+    if 'Conv2d' in kind or 'Linear' in kind:
+        for name in ('weight', 'bias'):
+            p = getattr(m, name, None)
+            if p is not None and hasattr(p, 'data'):
+                nn.init.constant_(p.data, 0.0)
+
+
+class STN3d(nn.Module):
+    """PointNet-style T-Net over the `num_points` samples of each proposal: three pointwise Conv1d + BatchNorm + ReLU
+    (3 -> 64 -> 128 -> 256), max over the samples, three Linear layers (256 -> 128 -> 64 -> 12, the first two with
+    BatchNorm + ReLU); the 12 outputs + identity are a 3 x 4 matrix [R | t] applied to the proposal's points.
+    Same attribute names (state_dict keys) and forward contract as pointnet2_modules.py:421-467:
+    grouped_xyz (B, 3, P, num_points) -> (B, 3, P, num_points)."""
+
+    def __init__(self, num_points=2500):
+        super().__init__()
+        self.num_points = num_points
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 256, 1)
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(256, 128), nn.Linear(128, 64), nn.Linear(64, 12)
+        self.relu = nn.ReLU(inplace=True)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(128), nn.BatchNorm1d(256)
+        self.bn4, self.bn5 = nn.BatchNorm1d(128), nn.BatchNorm1d(64)
+        self.apply(weights_init)
+
+    def forward(self, grouped_xyz):
+        B, _, P, _ = grouped_xyz.shape
+        pts = grouped_xyz.transpose(2, 1).contiguous().view(B * P, 3, self.num_points)
+        h = pts
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
+            h = self.relu(bn(conv(h)))
+        h = self.mp1(h).squeeze(2)
+        h = self.relu(self.bn4(self.fc1(h)))
+        h = self.relu(self.bn5(self.fc2(h)))
+        eye = torch.eye(3, 4, dtype=torch.float32, device=grouped_xyz.device).view(1, 12)
+        m = (self.fc3(h) + eye).view(B * P, 3, 4)
+        moved = torch.bmm(m[:, :, :3], pts) + m[:, :, 3:]
+        return moved.view(B, P, 3, -1).transpose(1, 2)
+
+
+class STN_Group(nn.Module):
+    """Ball-query grouping around the proposals, the neighbour offsets turned by each proposal's heading into its
+    canonical frame and then by the learned STN3d transform (pointnet2_modules.py:470-538).
+    forward(xyz (B,N,3), features (B,C,N), new_xyz (B,P,3), orientations (B,P)) ->
+    (grouped_xyz (B,3,P,nsample), grouped_features[, unique_cnt])."""
+
+    def __init__(self, radius: float = None, nsample: int = None, use_xyz: bool = True, normalize_xyz: bool = False,
+                 sample_uniformly: bool = False, ret_unique_cnt: bool = False):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.normalize_xyz, self.ret_unique_cnt = normalize_xyz, ret_unique_cnt
+        self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                                                     normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
+                                                     ret_unique_cnt=ret_unique_cnt)
+        self.stn3d = STN3d(num_points=nsample)
+
+    def forward(self, xyz, features=None, new_xyz=None, orientations=None):
+        got = self.grouper(xyz, new_xyz, features)
+        grouped_features, local = got[0], got[1]
+        B, P = orientations.shape
+        c, s = torch.cos(orientations), torch.sin(orientations)
+        zero, one = torch.zeros_like(c), torch.ones_like(c)
+        # rotation about z by -heading: rows (c, s, 0), (-s, c, 0), (0, 0, 1)
+        rot = torch.stack([c, s, zero, -s, c, zero, zero, zero, one], dim=-1).view(B * P, 3, 3)
+        local = torch.bmm(rot, local.transpose(1, 2).contiguous().view(B * P, 3, -1))
+        local = local.view(B, P, 3, -1).transpose(1, 2).contiguous()
+        out = (self.stn3d(local), grouped_features)
+        return out + (got[2],) if self.ret_unique_cnt else out
