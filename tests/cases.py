@@ -124,3 +124,10 @@ def fill_weights(net):
 def state_checksum(net):
     sd = net.state_dict()
     return float(sum(v.double().abs().sum() for k, v in sd.items() if v.is_floating_point()))
+
+
+def seam_cotangents(B, seed=77):
+    """Seeded cotangents on (vote_xyz, vote_features) at the backbone -> detection seam: fixture g10c back-propagates
+    these through the reference's backbone, the GPU test through ours."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 512, 3, generator=g), torch.randn(B, 512, 256, generator=g) * 0.1

@@ -15,6 +15,11 @@ tests/cases.py) and the reference's outputs.
       seeded random and adversarial clouds.  The reference has no CPU path and
       no tests for these, so G6 pins the *restatement* against regressions; it
       is not reference-generated ("parity unpinned").
+  G6b furthest_point_sampling / gather_points against the reference's OWN pure-torch
+      `farthest_point_sample` / `index_points` (net_utils/libs.py:152-190; random start
+      patched to index 0) on the tie-free, origin-free clouds: reference-generated
+      vectors for a1 / a2 (the CUDA kernel adds the |p|^2 <= 1e-3 skip and the block
+      tie rule, which these clouds do not exercise; margins recorded).
   G3-G5 are produced by tests/golden/make_model_golden.py (full model paths).
 """
 import os
@@ -215,7 +220,43 @@ def g6():
     print("g6", len(out), "arrays")
 
 
+def g6b():
+    """a1 / a2 pinned by reference-held code.  `libs.farthest_point_sample` is the textbook FPS: start at a random
+    point (patched to 0 = the CUDA kernel's start), keep min squared distance, take torch.max's index.  It has neither
+    the CUDA kernel's skip of points with |p|^2 <= 1e-3 nor its block-shaped tie rule, so the cases are the random
+    clouds without such points, and every pick's winner must lead the runner-up by > 4 float32 ulps (recorded), which
+    also makes the result independent of the summation order of dx^2 + dy^2 + dz^2."""
+    _ref_path()
+    from net_utils import libs
+    out = {}
+    real_randint = torch.randint
+    torch.randint = lambda lo, hi, size, **kw: torch.zeros(size, dtype=kw.get('dtype', torch.long))
+    try:
+        for (b, n, m, kind, seed) in cases.FPS_CASES:
+            if kind not in RANDOM_KINDS or n < 2 or n > 20000:
+                continue
+            xyz = cases.cloud(b, n, seed, kind)
+            if bool(((xyz ** 2).sum(-1) <= 2e-3).any()):
+                continue
+            _, gap = fps_margin(xyz, m)
+            if not gap > 4.0:
+                continue
+            key = f"{b}_{n}_{m}_{kind}_{seed}"
+            cent = libs.farthest_point_sample(xyz, m)                       # (b, m) int64
+            out["fps_" + key] = cent.numpy().astype(np.int32)
+            out["gap_" + key] = np.array(gap)
+            # gather: reference index_points on (B, N, C) rows == gather_points on (B, C, N) columns
+            g = torch.Generator().manual_seed(seed)
+            feats = torch.randn(b, 5, n, generator=g)
+            out["gather_" + key] = libs.index_points(feats.transpose(1, 2).contiguous(), cent).transpose(1, 2).contiguous().numpy()
+    finally:
+        torch.randint = real_randint
+    assert len([k for k in out if k.startswith('fps_')]) >= 6, sorted(out)
+    np.savez_compressed(os.path.join(HERE, "g6b_fps_ref.npz"), **out)
+    print("g6b", sorted(k for k in out if k.startswith('gap_')), [float(out[k]) for k in sorted(out) if k.startswith('gap_')])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g6", "g6b"]
     for w in which:
         globals()[w]()

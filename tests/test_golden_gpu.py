@@ -59,3 +59,20 @@ def test_g6_ext_ops(dev):
         d, i = _ext.three_nn(cases.cloud(b, n, seed, kind).to(dev), cases.cloud(b, m, seed + 50, kind).to(dev))
         assert np.array_equal(d.cpu().numpy(), z[f"nn3_{b}_{n}_{m}_{kind}_{seed}_dist2"])
         assert np.array_equal(i.cpu().numpy(), z[f"nn3_{b}_{n}_{m}_{kind}_{seed}_idx"])
+
+
+def test_g6b_fps_and_gather_vs_reference_torch_code(dev):
+    """HIP furthest_point_sampling / gather_points against the vectors of the reference's own pure-torch FPS /
+    index_points (net_utils/libs.py:152-190; tests/golden/make_golden.py g6b) -- no oracle involved."""
+    from pose2room_amd.pointnet2_ops import _ext
+    from tests.test_oracle_golden import _g6b_cases
+    z = np.load(os.path.join(G, "g6b_fps_ref.npz"))
+    seen = 0
+    for key, b, n, m, kind, seed in _g6b_cases(z):
+        xyz = cases.cloud(b, n, seed, kind).to(dev)
+        idx = _ext.furthest_point_sampling(xyz, m)
+        assert np.array_equal(idx.cpu().numpy(), z["fps_" + key]), key
+        feats = torch.randn(b, 5, n, generator=torch.Generator().manual_seed(seed)).to(dev)
+        assert np.array_equal(_ext.gather_points(feats, idx).cpu().numpy(), z["gather_" + key]), key
+        seen += 1
+    assert seen >= 6
