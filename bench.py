@@ -22,12 +22,15 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   h2d          -- the same run with the batch copied host -> device every step (pinned, prefetched);
   verify       -- what was checked at the bench shape BEFORE timing (finite losses of a train step; sample 0 of the
                   full batch against the same sample run alone with running-statistics BatchNorm);
-  roofline     -- the dominant kernel (gcn2_kernel) against the fp32 MFMA roof: MFMA FLOPs the kernel ISSUES per
-                  launch / its average duration INSIDE the step (HIP events around every launch of instrumented
-                  steps that follow the timed region); the dense-equivalent figure is a sub-key;
+  roofline     -- the dominant kernel (gcn3_kernel: graph-conv forward + data gradient) against the fp32 MFMA roof: MFMA
+                  FLOPs the kernel ISSUES per launch / its average duration INSIDE the step (HIP events around every
+                  launch of instrumented steps that follow the timed region);
   mfma_kernels -- the same for the other MFMA kernels of the ST-GCN blocks (in-step durations, issued FLOPs);
-  step_roofline-- the whole step: MFMA FLOPs issued per step (PMC profile) and the reference's algorithmic FLOPs;
-  kernels      -- event-timed durations of the pointnet2 / loss HIP kernels at the P2RNet shapes;
+  step_roofline-- the whole step: MFMA FLOPs issued per step (stored PMC profile) over this run's step time;
+  ddp          -- N > 1 only: per-rank step times, and the step time with the gradient all-reduce switched off
+                  (`no_sync`) next to the one with it = the all-reduce time that is NOT hidden under the backward pass;
+  kernels      -- event-timed durations of the pointnet2 / loss HIP kernels at the P2RNet shapes (`GBps_l2_assisted`:
+                  algorithmic bytes / time of a gather whose 17 MB source stays in L2 / MALL -- not an HBM rate);
   cpu_baseline -- the same host model on the host cores with the CPU oracle behind
                   the ops ("port"), on a bounded sample.
 """
@@ -207,7 +210,8 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
     ms = sum(per[t][0] * per[t][1] for t in g2) / n_g2             # launch-weighted mean, as rocprofv3 --stats shows it
     fl = sum(issued[t] * per[t][1] for t in g2) / n_g2
     tf = fl / ms / 1e9
-    traffic = _profile_json('r4_gcn3_pmc_traffic.json') or _profile_json('r3_gcn3_pmc_traffic.json')
+    traffic = (_profile_json('r5_gcn3_pmc_traffic.json') or _profile_json('r4_gcn3_pmc_traffic.json')
+               or _profile_json('r3_gcn3_pmc_traffic.json'))
     cols = batch_size * frames * 53
     scale = cols / float(32 * 1024 * 53)
     from pose2room_amd.p2rnet import gcn_op
@@ -221,18 +225,14 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
             'flops_per_launch': fl, 'flops': 'MFMA FLOPs issued (454 of 583 (plane, joint) units forward, 369 data gradient)',
             'ms_forward': round(per['gcn_forward'][0], 4) if 'gcn_forward' in per else None,
             'ms_data_gradient': round(per['gcn_data_gradient'][0], 4) if 'gcn_data_gradient' in per else None,
-            'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols,
-            'frac_dense_equivalent': round(dense / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-            'dense_equivalent': 'the operator with every (plane, joint) unit computed (the count rounds 1-2 quoted); '
-                                'the reference formulation (conv1x1 to 704 channels + dense einsum) would be '
-                                f'{round(ref / ms / 1e9, 1)} TFLOP/s'}
+            'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols}
     return roof, rows
 
 
 def step_mfma_issued(batch, frames):
     """MFMA FLOPs the step's kernels issue (SQ_VALU_MFMA_BUSY_CYCLES x 64 FLOP/cycle/SIMD summed over one step, PMC
     profile from tools/pmc_step_mfma.sh at bs=32, T=1024; linear in batch * frames).  (flops, source) or (None, None)."""
-    for name in ('r4_step_mfma.json', 'r3_step_mfma.json', 'r2_step_mfma.json'):
+    for name in ('r5_step_mfma.json', 'r4_step_mfma.json', 'r3_step_mfma.json', 'r2_step_mfma.json'):
         prof = _profile_json(name)
         if prof:
             return prof['mfma_busy_cycles_per_step'] * 64.0 * (batch * frames) / float(32 * 1024), 'profiles/' + name
@@ -322,7 +322,8 @@ def kernel_microbench(device):
         us = e0.elapsed_time(e1) * 1e3 / reps
         out[name] = {'us': round(us, 2)}
         if bytes_:
-            out[name]['GBps'] = round(bytes_ / us / 1e3, 1)
+            # the gathered source (B*C*N*4 = 17 MB) is L2 / MALL resident: an L2-assisted rate, not HBM bandwidth
+            out[name]['GBps_l2_assisted'] = round(bytes_ / us / 1e3, 1)
     return out
 
 
@@ -348,7 +349,11 @@ def cpu_baseline(frames, budget_s=25.0):
         dt = (time.time() - t0) / n
     torch.set_num_threads(prev_threads)
     return {'value': round(B / dt, 4), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} train steps of bs={B}, T={frames}, J=53 after 1 warm-up (host model + CPU oracle ops)'}
+            'sample': f'{n} train steps of bs={B}, T={frames}, J=53 after 1 warm-up (host model + CPU oracle ops)',
+            # the reference's OWN Python (imported, CPU restatement of `_ext` behind it) cannot travel to this box; it was
+            # timed in the survey container: same step, bs=2, T=1024
+            'reference_python': {'value': 0.58, 'unit': 'samples/s', 'cores': 8, 'kind': 'reference',
+                                 'where': 'survey container (8 host cores), BASELINE.md section 2; not measured in this run'}}
 
 
 def build_trainer_cpu(frames):
@@ -473,10 +478,31 @@ def main():
     # all-reduce -- rank 0 reports
     roof, rows = mfma_rooflines(trainer, batch, args.batch, args.frames)
 
+    ddp_info = None
+    if world > 1:
+        # (1) spread of the ranks' own step times; (2) the same K steps with the gradient all-reduce switched off
+        # (DDP.no_sync: hooks do not fire, gradients stay local) = what the all-reduce costs on top of a step, i.e. the
+        # part of it that is not hidden under the backward pass.  Runs last: the ranks' weights diverge under no_sync.
+        mine = torch.tensor([step_ms['median']], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(t.item()), 3) for t in every]
+
+        def step_no_sync():
+            with trainer.net.no_sync():
+                return trainer.train_step(dict(batch))
+        step_no_sync()
+        elapsed_ns, _, step_ms_ns = timed(step_no_sync)
+        ddp_info = {'rank_step_ms_median': per_rank, 'rank_spread_ms': round(max(per_rank) - min(per_rank), 3),
+                    'ms_per_step_no_sync': round(elapsed_ns / args.steps * 1e3, 3),
+                    'allreduce_exposed_ms_per_step': round((elapsed - elapsed_ns) / args.steps * 1e3, 3),
+                    'how': 'K more steps under DDP.no_sync() (no gradient all-reduce) against the timed K steps; the '
+                           '80-byte logging all-reduce is in both', 'gradient_bytes_per_step': 8176132,
+                    'backend': dist.get_backend()}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         sps = world * args.batch * args.steps / elapsed
-        tflops = sps * gflop_per_sample(args.frames) / 1e3
         line = {
             'metric': f'P2RNet train-step samples/sec (T={args.frames},J=53,bs={args.batch})', 'value': round(sps, 3),
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -495,6 +521,8 @@ def main():
                        'parallelism': f'dp{world}', 'loss_total': round(float(last['total']), 4)},
             'verify': verify,
         }
+        if ddp_info:
+            line['ddp'] = ddp_info
         line['roofline'] = roof
         line['mfma_kernels'] = rows
         issued, src = step_mfma_issued(args.batch, args.frames)
@@ -506,9 +534,7 @@ def main():
             'derived': 'the FLOP count is a stored PMC measurement (SQ_VALU_MFMA_BUSY_CYCLES x 64 summed over one step of '
                        'the build that profile was taken on, at bs=32, T=1024, scaled by batch x frames), not a counter '
                        'read in this run; the step time is this run\'s',
-            'frac_reference_algorithmic': round(tflops / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-            'reference_algorithmic': f'{gflop_per_sample(args.frames)} GFLOP/sample fwd+bwd of the REFERENCE step (dense '
-                                     'graph product), the count rounds 1-2 quoted as `frac`'}
+            'reference_algorithmic_gflop_per_sample': gflop_per_sample(args.frames)}
         if not args.no_microbench:
             line['kernels'] = kernel_microbench(device)
         if world == 1 and not args.no_cpu_baseline:

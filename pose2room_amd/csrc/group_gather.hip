@@ -15,11 +15,20 @@
 //            coalesced store; it keeps the four indices in registers and walks
 //            a chunk of channels, so the index tensor is read once per chunk,
 //            not once per channel.
-//  backward: the destination rows of a channel chunk (GC x n floats) live in
-//            LDS; the block scatter-adds with ds_add_f32 (no HBM atomics) and
-//            writes the finished rows out coalesced, overwriting grad_points
-//            -- no zero-fill pass, no read-modify-write traffic to HBM.  Rows
-//            too long for LDS fall back to global atomics on a zeroed buffer.
+//  backward: gather form, deterministic (round 5).  A workgroup stages the index
+//            list of its cloud and a chunk of GC gradient rows ([GC][S]) in LDS;
+//            every thread owns destination points and walks the index list IN
+//            ORDER (16-byte broadcast reads), adding the staged gradient of each
+//            hit to GC register accumulators: no atomics at all, the sum of a
+//            destination is taken in ascending slot order -- bit for bit the
+//            sequential loop of the CPU restatement -- and the rows leave with
+//            coalesced stores, overwriting grad_points (no zero-fill pass).
+//            The first form of this kernel scatter-added with ds_add_f32 from
+//            eight waves: order of arrival, i.e. run-to-run differences in the
+//            last bit of d features, which train-mode BatchNorm amplified to
+//            1e-3 of the backbone's gradients.  Index lists too long for LDS
+//            fall back to that form, rows too long for it to global atomics on
+//            a zeroed buffer (both order-free like the reference's atomics).
 #include "p2r_common.h"
 
 #include <algorithm>
@@ -91,6 +100,65 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_lds_kernel(
   for (int t = threadIdx.x; t < nl * n; t += GG_THREADS) gp[t] = s_acc[t];
 }
 
+// Deterministic gather form: LDS = idx [SP] ints + gradient rows [GC][SP] floats, SP = S rounded up to 4.
+// A thread owns the destinations tid, tid + GG_THREADS, ..; a slot whose index equals the destination adds its GC
+// staged values to the thread's accumulators.  Hits are rare (S / n per destination), the walk itself is one
+// broadcast 16-byte LDS read and four compares per four slots.
+template <int GC>
+__global__ __launch_bounds__(GG_THREADS) void group_grad_scan_kernel(
+    int c, int n, int S, int SP, int c_tiles, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points) {
+  extern __shared__ float s_raw[];
+  int *ids = reinterpret_cast<int *>(s_raw);          // [SP]
+  float *gl = s_raw + SP;                             // [GC][SP]
+  const int ct = blockIdx.x % c_tiles;
+  const int batch = blockIdx.x / c_tiles;
+  const int l0 = ct * GC;
+  const int nl = min(GC, c - l0);
+  const float *g = grad_out + ((size_t)batch * c + l0) * S;
+  const int *id = idx + (size_t)batch * S;
+  float *gp = grad_points + ((size_t)batch * c + l0) * n;
+
+  for (int t = threadIdx.x; t < SP; t += GG_THREADS) ids[t] = t < S ? id[t] : -1;
+  for (int l = 0; l < GC; ++l)
+    for (int t = threadIdx.x; t < SP; t += GG_THREADS) gl[l * SP + t] = (l < nl && t < S) ? g[(size_t)l * S + t] : 0.f;
+  __syncthreads();
+  for (int ii = threadIdx.x; ii < n; ii += GG_THREADS) {
+    float acc[GC];
+#pragma unroll
+    for (int l = 0; l < GC; ++l) acc[l] = 0.f;
+    for (int s4 = 0; s4 < SP; s4 += 4) {
+      const int4 q = *reinterpret_cast<const int4 *>(ids + s4);
+      const int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (qq[e] == ii) {
+#pragma unroll
+          for (int l = 0; l < GC; ++l) acc[l] += gl[l * SP + s4 + e];
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < GC; ++l)
+      if (l < nl) gp[(size_t)l * n + ii] = acc[l];
+  }
+}
+
+template <int GC>
+int group_grad_scan_launch(int b, int c, int n, int S, int SP, const float *grad_out, const int *idx, float *grad_points,
+                           hipStream_t st) {
+  const int c_tiles = p2r_cdiv(c, GC);
+  const long long blocks = (long long)b * c_tiles;
+  if (blocks > 0x7fffffffLL) return P2R_EINVAL;
+  const size_t lds = (size_t)(GC + 1) * SP * sizeof(float);
+  static unsigned char lds_ok[P2R_MAX_DEVICES];
+  hipError_t e = p2r_allow_big_lds(group_grad_scan_kernel<GC>, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(group_grad_scan_kernel<GC>, dim3((unsigned)blocks), dim3(GG_THREADS), lds, st, c, n, S, SP, c_tiles,
+                     grad_out, idx, grad_points);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
 // Fallback for rows longer than LDS: global atomics onto a zeroed buffer.
 __global__ __launch_bounds__(GP_THREADS) void group_grad_atomic_kernel(
     int c, int n, int S, long long total, const float *__restrict__ grad_out,
@@ -122,6 +190,16 @@ int group_forward(int b, int c, int n, int S, const float *points, const int *id
 int group_backward(int b, int c, int n, int S, const float *grad_out, const int *idx,
                    float *grad_points, hipStream_t st) {
   if (b == 0 || c == 0 || n == 0) return P2R_OK;
+  // deterministic gather form whenever the index list and at least 4 gradient rows fit the LDS
+  const int SP = (S + 3) & ~3;
+  const size_t per_row = (size_t)std::max(SP, 4) * sizeof(float);
+  const size_t fit = (152 * 1024) / per_row;            // rows of SP floats (one of them the index list)
+  if (S > 0 && fit >= 5) {
+    const int sp = std::max(SP, 4);
+    if (fit >= 17 && c > 8) return group_grad_scan_launch<16>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+    if (fit >= 9 && c > 4) return group_grad_scan_launch<8>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+    return group_grad_scan_launch<4>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+  }
   const size_t row_bytes = (size_t)n * sizeof(float);
   // Channel chunk: as many rows as fit 64 KiB of LDS (2 blocks / CU), up to 16,
   // while keeping >= ~512 blocks in flight when the problem is large enough.

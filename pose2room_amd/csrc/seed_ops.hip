@@ -300,6 +300,9 @@ extern "C" int p2r_nearest_prefix(int b, int t, int s, const float *cum, const f
                                   void *stream) {
   if (b < 0 || t <= 0 || s < 0 || t > 40000) return P2R_EINVAL;
   if (b == 0 || s == 0) return P2R_OK;
+  static unsigned char lds_ok[P2R_MAX_DEVICES];   // t > 16384: more than the 64 KB a kernel may use by default
+  hipError_t e = p2r_allow_big_lds(nearest_prefix_kernel, lds_ok, 40000 * (int)sizeof(float));
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nearest_prefix_kernel, dim3((unsigned)((s + 255) / 256), (unsigned)b), dim3(256),
                      (size_t)t * sizeof(float), p2r_stream(stream), t, s, cum, target, inds);
   P2R_LAUNCH_CHECK();

@@ -67,8 +67,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
     }
   };
 
+  // one slot per (wave, row, moment): plain read-modify-writes by the one lane that owns the row in its wave, summed
+  // over the waves in a fixed order at the end -- LDS atomics across waves made the sums (and with them every later
+  // BatchNorm of the step) depend on wave arrival order from run to run
   float *rowstat = hs + TC_C * row_len;
-  if (tid < 2 * TC_C) rowstat[tid] = 0.f;
+  for (int e = tid; e < (TC_THREADS / 64) * 2 * TC_C; e += TC_THREADS) rowstat[e] = 0.f;
 
   int tile = blockIdx.x;
   if (tile < total_tiles) issue_loads(tile);
@@ -169,14 +172,21 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tconv_fused_kernel(
           s1 = p2r_row16_sum(s1);
           s2 = p2r_row16_sum(s2);
           if (r == 0) {
-            atomicAdd(rowstat + 2 * row, s1);
-            atomicAdd(rowstat + 2 * row + 1, s2);
+            float *slot = rowstat + wave * 2 * TC_C + 2 * row;
+            slot[0] += s1;
+            slot[1] += s2;
           }
         }
       }
     __syncthreads();   // every wave is done with the LDS tile before it is overwritten
   }
-  if (stats_partial && tid < 2 * TC_C) stats_partial[(size_t)blockIdx.x * 2 * TC_C + tid] = rowstat[tid];
+  __syncthreads();   // (a workgroup without tiles reaches this point without having passed a barrier)
+  if (stats_partial && tid < 2 * TC_C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < TC_THREADS / 64; ++w) tot += rowstat[w * 2 * TC_C + tid];
+    stats_partial[(size_t)blockIdx.x * 2 * TC_C + tid] = tot;
+  }
 }
 
 // ---- weight gradient ------------------------------------------------------------------
@@ -443,7 +453,7 @@ static int tconv_forward_launch(int N, int T, int V, const float *x, const float
   const int tiles_per_seq = p2r_cdiv(T, F);
   int row_len = (F + 2 * HALO) * V;
   if (row_len % 2 == 0) ++row_len;               // odd stride: see stgcn_gcn.hip
-  const size_t lds = (size_t)TC_C * row_len * sizeof(float) + 2 * TC_C * sizeof(float);
+  const size_t lds = (size_t)TC_C * row_len * sizeof(float) + (size_t)(TC_THREADS / 64) * 2 * TC_C * sizeof(float);
   if (lds > 160 * 1024 || row_len > 512) return P2R_EINVAL;
   if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
   static unsigned char lds_ok[P2R_MAX_DEVICES];

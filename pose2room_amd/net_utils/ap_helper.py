@@ -30,7 +30,8 @@ _CORNER_SIGNS = [(-1, -1, -1), (+1, -1, -1), (+1, +1, -1), (-1, +1, -1),
 class PredMapCls(object):
     """One sample's `batch_pred_map_cls` entry -- the reference's list of (class, corners (8,3), score) tuples
     (ap_helper.py:294-350: class-major, then proposal index) -- held as the arrays it is made of.  It has the list's
-    length, iteration, indexing and equality semantics (tuples are made on demand), so everything written against
+    length, iteration and indexing (tuples are made on demand; `==` is object identity -- the reference's lists hold
+    arrays and have no usable equality either), so everything written against
     the reference's lists works; `eval_det.eval_det_multiprocessing_wo_mesh` reads the arrays directly
     (`class_arrays`) instead of walking ~2,800 tuples per sample.  Building the tuples eagerly was 60 % of the
     evaluation's wall time."""

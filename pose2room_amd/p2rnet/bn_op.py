@@ -100,6 +100,8 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
 
 OVERLAP_APPLY = True      # BatchNorm-backward apply pass on a side stream under the graph conv's gradient kernels
 OVERLAP_REDUCE = True     # ... and its reduction pass too (the data-gradient kernel then runs without the sums epilogue)
+SIDE_INLINE = False       # tests only: the very same launches as with the overlap on, but issued on the MAIN stream -- what
+#                           the side-stream schedule must reproduce bit for bit (a missed join would not)
 _SIDE = {}
 
 
@@ -228,7 +230,9 @@ class _FusedBNAct(Function):
                                                 _lib.current_stream(dev)), "bn_bwd_apply")
             return tot_, dx_, dres_
 
-        if side_ok:
+        if side_ok and SIDE_INLINE:
+            tot, dx, dres = apply_pass()
+        elif side_ok:
             # dy and the sums were complete at `ready` (recorded right behind the graph conv's data-gradient launch), but
             # this stream still has that op's weight- and adjacency-gradient kernels queued in front of us: ~2 ms of
             # MFMA-bound work that nothing here depends on and that leaves 100+ VGPRs per SIMD and two thirds of the

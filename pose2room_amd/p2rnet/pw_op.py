@@ -407,6 +407,22 @@ class _ProposalHeads(Function):
         return (None, dfeat, None, None, None) + tuple(grads)
 
 
+def _mixture_noise(e, mu, n_rows, name):
+    """Caller-supplied noise (the eps dict or `mdn.noise_hook`) as the read-out kernel reads it: (n_rows, G, 1, D)
+    values of mu's dtype, contiguous, on mu's device.  The module chain (`eps * sigma + mu`, mdn.py:40-47) broadcasts
+    and type-promotes; the kernel takes a raw pointer, so the same is done here (a float32 draw for the float64
+    heading head is widened, a broadcastable shape is expanded) and anything else is an error."""
+    want = (n_rows, mu.shape[0], 1, mu.shape[1])
+    if not torch.is_tensor(e):
+        raise TypeError(f"mixture noise for '{name}' must be a tensor, got {type(e).__name__}")
+    if tuple(e.shape) != want:
+        try:
+            e = e.expand(want)
+        except RuntimeError:
+            raise ValueError(f"mixture noise for '{name}' has shape {tuple(e.shape)}, expected {want}") from None
+    return e.to(device=mu.device, dtype=mu.dtype).contiguous()
+
+
 def proposal_heads(net, features, eps, return_pi=False):
     """-> (pred_center (B,3,K), pred_size (B,3,K), pred_heading (B,2,K) f64, sem_obj_feature (B,2+C,K)) as the module
     chain of ProposalNet.forward returns them (transposed views of (B,K,D) memory, which is the order `decode_scores`
@@ -422,7 +438,7 @@ def proposal_heads(net, features, eps, return_pi=False):
         draws = []
         for name, gm in zip(_HEADS, gmms):
             e = (eps or {}).get(name)
-            draws.append(e if e is not None else gm.mdn._eps(n_rows, 1))
+            draws.append(_mixture_noise(e if e is not None else gm.mdn._eps(n_rows, 1), gm.mdn.mu, n_rows, name))
     pc, ps, ph, sem, logits = _ProposalHeads.apply(net, features, draws[0], draws[1], draws[2],
                                                    *_proposal_params(net))
     out = (pc.transpose(1, 2), ps.transpose(1, 2), ph.transpose(1, 2), sem.transpose(1, 2))
@@ -443,7 +459,9 @@ def vote_head_supported(module, seed_features):
               and len(seq) == 3 and hasattr(seq[0], 'batchnorm') and hasattr(seq[1], 'batchnorm')
               and not hasattr(seq[2], 'batchnorm') and seq[0].conv.out_channels == 256
               and seq[1].conv.out_channels == 256 and seq[0].conv.bias is None and seq[1].conv.bias is None
-              and seq[2].conv.bias is not None and seq[0].batchnorm.training == seq[1].batchnorm.training)
+              and seq[2].conv.bias is not None and seq[0].batchnorm.training == seq[1].batchnorm.training
+              # the backward runs p2r_pw_gemm with k = R (rounded up to 16) against its PW_KMAX = 560 rows of LDS
+              and ((seq[2].conv.out_channels + 15) & ~15) <= 560 and seq[2].conv.in_channels == 256)
         return bool(ok)
     except (AttributeError, IndexError, TypeError):
         return False

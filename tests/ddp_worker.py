@@ -5,7 +5,8 @@ over gloo with every rank on cuda:0 when P2R_BENCH_SHARE_GPU=1), feeds each rank
 seeded synthetic dataset through P2RNet_dataloader, runs two train steps and checks:
   * every parameter is bit-identical on all ranks afterwards (the gradients were all-reduced),
   * the ranks saw different samples,
-  * DDP reduced the gradients in the bucket layout DESIGN.md section 7 states (f32 payload in one bucket).
+  * DDP reduced the gradients in the bucket layout DESIGN.md section 7 states (f32 payload in one bucket),
+  * the all-reduced gradients are bit-equal with the BatchNorm-backward passes on the side stream and inline.
 Rank 0 prints one JSON line."""
 import json
 import os
@@ -34,7 +35,8 @@ def main():
         dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
     import bench
     from pose2room_amd.p2rnet.dataloader import P2RNet_dataloader, SyntheticPoseDataset
-    frames, per_rank = 64, 2
+    frames, per_rank = 512, 2          # >= 512 frames: the seed frames are distinct (the real configuration; below that
+    #                                    ATen's index backward adds duplicates with atomics and the step is not bit-reproducible)
     trainer, cfg = bench.build_trainer(device, frames, world)
     cfg.config['device']['distributed'] = True
     cfg.config['train']['batch_size'] = per_rank
@@ -82,8 +84,36 @@ def main():
         dst = probe.to(device, non_blocking=True)
         torch.cuda.current_stream(device).synchronize()
         assert dst.device.index == local_rank
+    # The BatchNorm-backward passes that run on a side stream under gcn3_dw / gcn3_dcoef (bn_op.OVERLAP_APPLY +
+    # OVERLAP_REDUCE) must have joined the main stream before DDP's hooks read the gradients they feed: the all-reduced
+    # gradients are bit-equal with the passes on the side stream and with the very same launches issued on the main
+    # stream (bn_op.SIDE_INLINE) -- same batch, same mixture noise, same weights, three rounds each.
+    from pose2room_amd.p2rnet import bn_op
+    assert bn_op.OVERLAP_APPLY and bn_op.OVERLAP_REDUCE
+    fixed = trainer.to_device(dict(batch))
+
+    def reduced_grads(inline):
+        bn_op.SIDE_INLINE = inline
+        try:
+            trainer.net.zero_grad()
+            torch.manual_seed(1000 + rank)
+            est = trainer.net(dict(fixed))
+            trainer.net.module.loss(est, fixed)['total'].backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in trainer.net.module.named_parameters()}
+        finally:
+            bn_op.SIDE_INLINE = False
+    base = reduced_grads(True)
+    report = []
+    for rnd in range(3):
+        for inline in (True, False):
+            got = reduced_grads(inline)
+            differ = [n for n in base if not torch.equal(base[n], got[n])]
+            worst = max([((base[n] - got[n]).abs().max() / (base[n].abs().max() + 1e-30)).item() for n in differ] or [0.0])
+            report.append((rnd, 'main' if inline else 'side', len(differ), worst, differ[:3]))
+    assert all(r[2] == 0 for r in report), f'reduced gradients differ from the one-stream order: {report}'
     if rank == 0:
-        print(json.dumps({'world': world, 'backend': dist.get_backend(), 'steps': i + 1,
+        print(json.dumps({'world': world, 'side_stream_equals_one_stream': True, 'backend': dist.get_backend(), 'steps': i + 1,
                           'loss_total': losses['total'],
                           'bucket_sizes': str(log.get('bucket_sizes', '')),
                           'num_buckets': int(log.get('num_buckets_reduced', -1)) if 'num_buckets_reduced' in log else None,

@@ -26,5 +26,9 @@ def test_bench_two_ranks_share_gpu():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 8 and line['scaling'] == 'weak'
     assert line['value'] > 0 and line['config']['parallelism'] == 'dp2'
+    # multi-rank report: each rank's own step time and the cost of the gradient all-reduce (steps with / without it)
+    ddp = line['ddp']
+    assert len(ddp['rank_step_ms_median']) == 2 and all(v > 0 for v in ddp['rank_step_ms_median'])
+    assert ddp['ms_per_step_no_sync'] > 0 and 'allreduce_exposed_ms_per_step' in ddp and ddp['backend'] == 'gloo'
     # gradients must arrive in the layout DDP's bucket views expect (no silent extra copies)
     assert 'strides' not in out.stderr, out.stderr[-2000:]

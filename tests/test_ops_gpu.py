@@ -56,7 +56,20 @@ def test_group_points_and_grad(ext, oracle, dev, b, c, n, p, s, seed):
     go = torch.randn(b, c, p, s, generator=g)
     wg = oracle.OracleExt.group_points_grad(go, idx, n)
     gg = ext.group_points_grad(go.to(dev), idx.to(dev), n).cpu()
-    torch.testing.assert_close(gg, wg, rtol=1e-5, atol=1e-5)
+    # gather form (round 5): every destination sums its slots in ascending order, like the sequential CPU loop -- bit-exact
+    # and the same from run to run (no atomics)
+    assert torch.equal(gg, wg)
+    assert torch.equal(ext.group_points_grad(go.to(dev), idx.to(dev), n).cpu(), gg)
+
+
+def test_group_points_grad_long_index_list_falls_back(ext, oracle, dev):
+    """an index list too long for LDS (S = 40000 slots) takes the order-free scatter forms: 1e-5 like the reference's atomics"""
+    g = torch.Generator().manual_seed(8)
+    b, c, n, p, s = 1, 6, 700, 2500, 16
+    idx = torch.randint(0, n, (b, p, s), generator=g, dtype=torch.int32)
+    go = torch.randn(b, c, p, s, generator=g)
+    torch.testing.assert_close(ext.group_points_grad(go.to(dev), idx.to(dev), n).cpu(),
+                               oracle.OracleExt.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("b,c,n,m,seed", [(2, 3, 512, 128, 1), (1, 7, 100, 100, 2), (2, 256, 64, 9, 3)])
@@ -67,8 +80,8 @@ def test_gather_points_and_grad(ext, oracle, dev, b, c, n, m, seed):
     assert torch.equal(ext.gather_points(pts.to(dev), idx.to(dev)).cpu(),
                        oracle.OracleExt.gather_points(pts, idx))
     go = torch.randn(b, c, m, generator=g)
-    torch.testing.assert_close(ext.gather_points_grad(go.to(dev), idx.to(dev), n).cpu(),
-                               oracle.OracleExt.gather_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    assert torch.equal(ext.gather_points_grad(go.to(dev), idx.to(dev), n).cpu(),
+                       oracle.OracleExt.gather_points_grad(go, idx, n))          # ascending-slot sums, no atomics
 
 
 @pytest.mark.parametrize("b,n,m,kind,seed", [(2, 512, 128, "uniform", 1), (2, 100, 2, "uniform", 2),
