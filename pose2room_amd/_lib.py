@@ -9,7 +9,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2r_hip.so")
+# P2R_LIB_PATH: another build of the SAME library (A/B timing of kernel variants on one box, tools/ab_bench.sh); the
+# loader's checks (ABI version, every declared symbol) apply to it unchanged
+LIB_PATH = os.environ.get("P2R_LIB_PATH") or os.path.join(_HERE, "libp2r_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "p2r_hip.h")
 
 ABI_VERSION = 2     # p2r_abi_version() of the library this loader was written against (include/p2r_hip.h)

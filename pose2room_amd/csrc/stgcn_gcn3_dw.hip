@@ -187,14 +187,23 @@ __device__ __forceinline__ void w3_wave_main(const W3Params &p, float *lds, cons
     cso[i] = idx < 64 * V ? (idx / V) * RL + idx % V : 0;
   }
 
-  int tile = blockIdx.x;
+  // Tile order (round 5).  A tile row is 848 bytes of a 3,392-byte-per-16-frames channel row: 6.6 cache lines, so
+  // neighbouring tiles share a line at each end.  With tile = blockIdx + i * grid the two owners of a shared line sat
+  // on different XCDs (block b runs on XCD b % 8), each XCD's L2 fetched the line for itself and the launch moved
+  // 1.22x its algorithmic bytes (profiles/r4_gcn3_pmc_traffic.json).  Now the 32 workgroups of an XCD walk 32
+  // CONSECUTIVE tiles per round: the shared lines are hits in that XCD's L2.
+  const int per_xcd = (gridDim.x & 7) == 0 ? (int)(gridDim.x >> 3) : 0;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  auto tile_of = [&](int i) { return per_xcd ? (i * 8 + xcd) * per_xcd + slot : (int)(blockIdx.x + i * gridDim.x); };
+  int it = 0;
+  int tile = tile_of(0);
   // Staggered start: the copy of a tile cannot overlap its own workgroup's MFMAs (no room for a second pair of
   // tiles), and workgroups running in lock-step all copy at the same moments -- 28 MB per round at the HBM rate,
   // with every matrix pipe idle.  A quarter of the workgroups each start 0 / 3.5 / 7 / 10.5 us late, so some
   // compute while others copy (measured: 1.03 -> 0.94 ms).
-  for (int d = 0; d < (int)(blockIdx.x & 3); ++d) __builtin_amdgcn_s_sleep(127);
+  for (int d = 0; d < (int)((per_xcd ? slot : blockIdx.x) & 3); ++d) __builtin_amdgcn_s_sleep(127);
   if (tile < p.total_tiles) copy_tile(tile);
-  for (; tile < p.total_tiles; tile += gridDim.x) {
+  for (; tile < p.total_tiles; tile = tile_of(++it)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own pieces have landed
     __syncthreads();                                       // ... everybody's
 
@@ -211,7 +220,7 @@ __device__ __forceinline__ void w3_wave_main(const W3Params &p, float *lds, cons
     else if constexpr (SET == 2) { W3_BODY_2 } else { W3_BODY_3 }
 
     __syncthreads();                                       // nobody reads the tiles any more
-    const int ntile = tile + gridDim.x;
+    const int ntile = tile_of(it + 1);
     if (ntile < p.total_tiles) copy_tile(ntile);
   }
 

@@ -37,15 +37,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int T3_F = 16, T3_CP = 16, T3_NPH = 4, T3_NW = 8, T3_SLOTS = 7, T3_V = 53;
 constexpr int T3_ST = 3;   // floats per (wave, row) statistics entry: (sum, sum of squares) about the pivot, pivot
 constexpr int T3_RS = T3_F * T3_V;                  // 848
-constexpr int T3_MAIN = T3_CP * T3_RS;              // floats of the 16-frame part of a slice
-constexpr int T3_HRS = 2 * T3_V;                    // halo row: frame t0-1, frame t0+16
-constexpr int T3_HALO = T3_CP * T3_HRS;
-constexpr int T3_BUF = T3_MAIN + T3_HALO;           // floats per phase buffer (61,056 bytes)
-constexpr int T3_NV4 = T3_MAIN / 4;
-constexpr int T3_PIECES16 = (T3_NV4 + 63) / 64;     // 53
-constexpr int T3_PW16 = (T3_PIECES16 + T3_NW - 1) / T3_NW;     // 7 per wave
-constexpr int T3_PIECESH = (T3_HALO + 63) / 64;     // 27
-constexpr int T3_PWH = (T3_PIECESH + T3_NW - 1) / T3_NW;       // 4 per wave
+// LDS image of a slice (round 5): 16 channel rows of T3_RSP floats; a row is a contiguous WINDOW of the tensor's channel
+// row -- [3 unused][frame t0-1][frames t0 .. t0+15][frame t0+16][19 unused] -- so the halo frames of the three-tap
+// instances arrive with the same 16-byte DMA stream as the slice itself (frame t0 sits 56 floats = 14 pieces into the
+// window: 16-byte aligned on both sides), and EVERY tap reads frame r + tap - 1 at one stride of 53 floats.  Row stride
+// 976 = 16 mod 32: the two channel rows of a 32-lane read group use disjoint banks (21 r and 16 + 21 r, r < 16).
+// Before, the halo frames lived in a separate [16][2 x 53] area filled by 27 four-byte DMA instructions per slice; the
+// one lane of a group that read there landed on a bank its group already used in taps 0 and 2: one extra LDS cycle on a
+// two-cycle read = the 28-39 % SQ_LDS_BANK_CONFLICT of profiles/r4_tconv_mfma_util.json.
+// Single-tap instances keep the plain [16][848] image.
+constexpr int T3_RSP3 = 976;                        // window length of the three-tap instances (floats)
+constexpr int T3_OFF3 = 56;                         // frame t0 inside the window
+constexpr int T3_BUF = T3_CP * T3_RSP3;             // floats per phase buffer (62,464 bytes; single-tap: 54,272 used)
 
 struct T3Params {
   int T, tiles_per_seq, total_tiles;
@@ -139,8 +142,12 @@ template <bool XFORM, bool BWD, int TAPS, int WAVE, bool ADDCT = false>
 __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, const float *__restrict__ x,
                                              const float *__restrict__ Wp, float *__restrict__ out, bool want_stats,
                                              const float *__restrict__ bwd_z, const float *__restrict__ add_ct = nullptr) {
-  constexpr int V = T3_V, NW = T3_NW, SLOTS = T3_SLOTS, RS = T3_RS, MAIN = T3_MAIN, HRS = T3_HRS, HALO = T3_HALO,
-                BUF = T3_BUF, NV4 = T3_NV4;
+  constexpr int V = T3_V, NW = T3_NW, SLOTS = T3_SLOTS, RS = T3_RS, BUF = T3_BUF;
+  constexpr int RSP = TAPS > 1 ? T3_RSP3 : RS;        // LDS row stride = window length
+  constexpr int OFF0 = TAPS > 1 ? T3_OFF3 : 0;        // frame t0 inside a row
+  constexpr int NV4 = T3_CP * RSP / 4;                // 16-byte pieces of a slice: 3904 = 61 x 64 / 3392 = 53 x 64
+  constexpr int PIECES16 = NV4 / 64;
+  static_assert(NV4 == PIECES16 * 64, "partial piece");
   constexpr int wave = WAVE;
   // joints of this wave: consecutive runs 7,7,7,7,6,6,6,6 = joints 0..51; joint 52 is split by its four 16-row blocks
   // over waves 4..7.  Waves w and w + 4 share a SIMD: 13.25 units per tap on each (with whole joints only, 53 joints
@@ -151,7 +158,7 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   constexpr int MQ = WAVE >= 4 ? WAVE - 4 : 0;
   constexpr int JQ = T3_V - 1;
   constexpr int NU = nslots + (QUARTER ? 1 : 0);       // units per tap visit (the last one a quarter)
-  constexpr int PW16 = T3_PW16, PWH = TAPS > 1 ? T3_PWH : 0;
+  constexpr int PW16 = (PIECES16 + NW - 1) / NW;
   float *rowstat = lds + 2 * BUF;                     // [NW][64][T3_ST]
   float *aff = rowstat + NW * 64 * T3_ST;                  // [64][2] (scale, shift) of the input transform
   float *bias_l = aff + 128;                          // [64]
@@ -163,8 +170,8 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   const size_t row_stride = (size_t)p.T * V;
   const float fillv = XFORM ? __int_as_float(0x7fc00000) : 0.f;   // outside the sequence: NaN -> relu gives the zero padding
 
-  // lane's read position inside a buffer for (tap, k-step s): channel 4s+g, frame r+tap-(TAPS-1)/2, the wave's first
-  // joint (halo rows for frames -1 / 16); the slot's joint is an immediate
+  // lane's read position inside a buffer for (tap, k-step s): channel 4s+g, frame r+tap-(TAPS-1)/2 (-1 .. 16: the halo
+  // frames are part of the row), the wave's first joint; the slot's joint is an immediate
   unsigned rd[TAPS][4];
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp) {
@@ -172,41 +179,43 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = 4 * s + g;
-      rd[tp][s] = (unsigned)((f < 0 ? MAIN + ch * HRS : (f >= T3_F ? MAIN + ch * HRS + V : ch * RS + f * V)) + j0) * 4u;
+      rd[tp][s] = (unsigned)(ch * RSP + OFF0 + f * V + j0) * 4u;
     }
   }
 
-  // this wave's DMA pieces of a slice; offsets relative to (channel row 0 of the slice, frame t0 - 1)
-  unsigned moff[PW16], hoff[PWH > 0 ? PWH : 1];
-  unsigned hmask = 0;                                 // bit i: this lane's element of halo piece i is frame t0+16 (else t0-1)
+  // this wave's DMA pieces of a slice; offsets relative to the start of channel row 0's window (frame t0, minus OFF0
+  // floats).  lmask / rmask, bit i: this lane's piece i lies in the window's part in front of frame t0 / behind frame
+  // t0+15 -- read only when that side of the tile is inside the sequence
+  unsigned moff[PW16];
+  unsigned lmask = 0, rmask = 0;
 #pragma unroll
   for (int i = 0; i < PW16; ++i) {
     const int pc = i * NW + wave, e = pc * 64 + lane;
-    const int row = e / (RS / 4), c4 = e - row * (RS / 4);
-    moff[i] = (pc < T3_PIECES16 && e < NV4) ? (unsigned)(((size_t)row * row_stride + V + 4 * c4) * sizeof(float)) : 0xffffffffu;
+    const int row = e / (RSP / 4), c4 = e - row * (RSP / 4);
+    moff[i] = pc < PIECES16 ? (unsigned)(((size_t)row * row_stride + 4 * c4) * sizeof(float)) : 0xffffffffu;
+    if (TAPS > 1 && pc < PIECES16) {
+      lmask |= (unsigned)(c4 < OFF0 / 4) << i;
+      rmask |= (unsigned)(c4 >= (OFF0 + RS) / 4) << i;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < PWH; ++i) {
-    const int pc = i * NW + wave, e = pc * 64 + lane;
-    const int row = e / HRS, q = e - row * HRS;
-    const int h = q >= V ? 1 : 0, v = q - h * V;
-    hoff[i] = (pc < T3_PIECESH && e < HALO) ? (unsigned)(((size_t)row * row_stride + (h ? RS + V : 0) + v) * sizeof(float)) : 0xffffffffu;
-    hmask |= (unsigned)h << i;
-  }
-  // base = address of (channel row 0 of the slice, frame t0 - 1); lo / hi: frame t0-1 / t0+16 exists in the sequence
-  // halo pieces first: the N16 main pieces are then the last vector-memory operations of the wave (t3_wait_a<N16>)
-  constexpr int N16 = (T3_PIECES16 - WAVE + NW - 1) / NW;   // every piece is whole: NV4 = 53 * 64
-  static_assert(T3_NV4 == T3_PIECES16 * 64, "partial main piece");
+  // base = address of channel row 0's window; lo / hi: frame t0-1 / t0+16 exists in the sequence.  Inside a sequence
+  // (62 of 64 tiles at T = 1024) every piece is one unconditional DMA; at its ends the pieces outside are not read (the
+  // window would leave the channel row -- at the first and last row of the tensor, the allocation) but filled with the
+  // padding value.  Either way a wave issues N16 vector-memory operations per slice (t3_wait_vm<N16>): the 32 pieces
+  // of a row boundary never fill a whole 64-lane instruction.
+  constexpr int N16 = (PIECES16 - WAVE + NW - 1) / NW;
   auto copy_slice = [&](float *buf, const float *base, bool lo, bool hi) {
+    if (TAPS == 1 || (lo && hi)) {
 #pragma unroll
-    for (int i = 0; i < PWH; ++i)
-      if (hoff[i] != 0xffffffffu) {
-        const bool in = ((hmask >> i) & 1u) ? hi : lo;
-        if (in) t3_dma4(base, hoff[i], buf + MAIN + (i * NW + wave) * 64);
-        else buf[MAIN + (i * NW + wave) * 64 + lane] = fillv;
+      for (int i = 0; i < N16; ++i) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N16; ++i) {
+        const bool outside = (((lmask >> i) & 1u) && !lo) || (((rmask >> i) & 1u) && !hi);
+        if (!outside) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
+        else *reinterpret_cast<float4 *>(buf + (i * NW + wave) * 256 + lane * 4) = float4{fillv, fillv, fillv, fillv};
       }
-#pragma unroll
-    for (int i = 0; i < N16; ++i) t3_dma16(base, moff[i], buf + (i * NW + wave) * 256);
+    }
   };
 
   f32x4 acc[SLOTS][4];
@@ -230,7 +239,7 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   int tile = blockIdx.x;
   if (tile < p.total_tiles) {       // prologue: phase 0 of the first tile
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * T3_F;
-    copy_slice(lds, x + (size_t)seq * 64 * row_stride + (size_t)t0 * V - V, t0 > 0, t0 + T3_F < p.T);
+    copy_slice(lds, x + (size_t)seq * 64 * row_stride + (size_t)t0 * V - OFF0, t0 > 0, t0 + T3_F < p.T);
   }
   t3_load_a<1>(a_base(0, 0), a_lane);
 
@@ -283,7 +292,7 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
       float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
       const bool copy = ph + 1 < T3_NPH || has_next;
       const bool same = ph + 1 < T3_NPH;
-      const float *src = (same ? xg + (size_t)(ph + 1) * T3_CP * row_stride : nxg) - V;
+      const float *src = (same ? xg + (size_t)(ph + 1) * T3_CP * row_stride : nxg) - OFF0;
       const bool slo = same ? t0 > 0 : nt0 > 0, shi = same ? t0 + T3_F < p.T : nt0 + T3_F < p.T;
       if (XFORM) {
         // BatchNorm affine + ReLU once per element, in place in the slice that has just landed
@@ -295,8 +304,8 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
           const int row = tid >> 5, col = tid & 31;
           const int ch = T3_CP * ph + row;
           const float sc = aff[2 * ch], sh = aff[2 * ch + 1];
-          float4 *rp = reinterpret_cast<float4 *>(cur + row * RS) + col;
-          constexpr int R4 = RS / 4;                      // 212 float4 per row
+          float4 *rp = reinterpret_cast<float4 *>(cur + row * RSP) + col;
+          constexpr int R4 = TAPS > 1 ? (OFF0 + RS + V + 3) / 4 : RS / 4;      // float4 per row: 240 (halo frames included) / 212
 #pragma unroll
           for (int it = 0; it < (R4 + 31) / 32; ++it)
             if (32 * it + 31 < R4 || 32 * it + col < R4) {
@@ -306,11 +315,6 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
               rp[32 * it] = v;
             }
         }
-        if (TAPS > 1)
-          for (int e = tid; e < HALO; e += NW * 64) {
-            const int ch = T3_CP * ph + e / HRS;
-            cur[MAIN + e] = fmaxf(fmaf(cur[MAIN + e], aff[2 * ch], aff[2 * ch + 1]), 0.f);
-          }
         __syncthreads();
       }
 
@@ -467,10 +471,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
             if (m + 1 < 4) load_z(m + 1, rr);
           }
         } else {
+          constexpr int SV4 = T3_CP * RS / 4;                // float4 of the 16-row staging tile
 #pragma unroll
-          for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
+          for (int it = 0; it < (SV4 + NW * 64 - 1) / (NW * 64); ++it) {
             const int e = it * NW * 64 + tid;
-            if (e < NV4) {
+            if (e < SV4) {
               const int row = e / (RS / 4), c4 = e - row * (RS / 4);
               orow[(size_t)row * (row_stride / 4) + c4] = srow[e];
             }
