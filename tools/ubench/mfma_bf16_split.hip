@@ -48,7 +48,12 @@ __device__ __forceinline__ void split2(const float (&x)[8], bf8 &p1, bf8 &p2) {
 }
 
 // MODE 0: f32 MFMA; 1: bf16 single term; 3: 3-term split; 6: 6-term split
-template <int MODE>
+// AGG: the B operand is a two-entry aggregate c0 x(col) + c1 x(col') built with FMAs from two LDS gathers per value, like
+//      a (plane, joint) unit of the graph conv (average neighbour-list length 2.1) -- the split then follows the combine;
+// REUSE: the (split) B operand feeds REUSE sets of A operands (3 = the taps of the temporal conv, whose B operand is the
+//      input itself: one split serves three times the MFMAs).  Timing-only variants: the stored result is checked for
+//      AGG = 0, REUSE = 1.
+template <int MODE, int AGG = 0, int REUSE = 1>
 __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__restrict__ W, const float *__restrict__ X,
                                                    float *__restrict__ Y, int store) {
   extern __shared__ float xs[];                        // [C][RS]
@@ -89,11 +94,17 @@ __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__res
         float b[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) b[s] = xb[4 * s * RS];
+        if constexpr (AGG) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[s] = fmaf(xb[4 * s * RS + 16], 0.75f, b[s] * 1.25f);
+        }
         asm volatile("" ::: "memory");      // the tile is re-read every pass, like a new tile would be
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int u = 0; u < REUSE; ++u)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m], 0, 0, 0);
+          for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m], 0, 0, 0);
       }
       finish(t, acc);
     }
@@ -128,6 +139,10 @@ __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__res
           float x[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) x[i] = xb[i * RS];
+          if constexpr (AGG) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fmaf(xb[i * RS + 16], 0.75f, x[i] * 1.25f);
+          }
           bf8 b1, b2, b3;
           if constexpr (NP == 1) {
 #pragma unroll
@@ -141,9 +156,12 @@ __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__res
           // dependence); smallest terms first, the accumulator sees them before the leading product
 #define TERM(ap, bp)                                                                                                 \
   _Pragma("unroll") for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ap][h][m], bp, acc[m], 0, 0, 0);
-          if constexpr (NP == 3) { TERM(0, b3) TERM(1, b2) TERM(2, b1) }
-          if constexpr (NP >= 2) { TERM(0, b2) TERM(1, b1) }
-          TERM(0, b1)
+#pragma unroll
+          for (int u = 0; u < REUSE; ++u) {
+            if constexpr (NP == 3) { TERM(0, b3) TERM(1, b2) TERM(2, b1) }
+            if constexpr (NP >= 2) { TERM(0, b2) TERM(1, b1) }
+            TERM(0, b1)
+          }
 #undef TERM
         }
       }
@@ -154,16 +172,16 @@ __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__res
   if (!store && checksum == 123.456f) Y[0] = checksum;
 }
 
-template <int MODE>
+template <int MODE, int AGG = 0, int REUSE = 1>
 void run(const char *name, const float *W, const float *X, float *Y, const std::vector<double> &ref, double ref_max,
          int blocks, double base_ms[1]) {
   const size_t lds = (size_t)C * RS * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(kern<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&kern<MODE, AGG, REUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipFuncAttributes attr;
-  hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern<MODE>));
+  hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&kern<MODE, AGG, REUSE>));
   // accuracy: one pass, stored
   hipMemset(Y, 0, (size_t)blocks * C * N * sizeof(float));
-  hipLaunchKernelGGL(kern<MODE>, dim3(blocks), dim3(NW * 64), lds, 0, 1, W, X, Y, 1);
+  hipLaunchKernelGGL((kern<MODE, AGG, REUSE>), dim3(blocks), dim3(NW * 64), lds, 0, 1, W, X, Y, 1);
   hipDeviceSynchronize();
   std::vector<float> y((size_t)C * N);
   hipMemcpy(y.data(), Y, y.size() * sizeof(float), hipMemcpyDeviceToHost);
@@ -172,22 +190,26 @@ void run(const char *name, const float *W, const float *X, float *Y, const std::
   // rate: ~50 ms
   const int iters0 = 200;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(kern<MODE>, dim3(blocks), dim3(NW * 64), lds, 0, iters0, W, X, Y, 0);
+  hipLaunchKernelGGL((kern<MODE, AGG, REUSE>), dim3(blocks), dim3(NW * 64), lds, 0, iters0, W, X, Y, 0);
   hipDeviceSynchronize();
   float ms = 0;
   int iters = iters0;
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern<MODE>, dim3(blocks), dim3(NW * 64), lds, 0, iters, W, X, Y, 0);
+    hipLaunchKernelGGL((kern<MODE, AGG, REUSE>), dim3(blocks), dim3(NW * 64), lds, 0, iters, W, X, Y, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     if (rep == 0) iters = (int)(iters * 50.0 / ms) + 1;
   }
-  const double flop = 2.0 * C * C * N * (double)iters * blocks;
+  const double flop = 2.0 * C * C * N * (double)iters * blocks * REUSE;
   const double tf = flop / ms / 1e9;
   if (MODE == 0) base_ms[0] = ms / iters;
-  printf("%-7s %8.3f us/pass  %7.1f fp32-equivalent TFLOP/s  x%4.2f vs f32 MFMA   VGPRs %3d  max err %.3e (%.2e of range)\n",
-         name, ms / iters * 1e3, tf, base_ms[0] / (ms / iters), attr.numRegs, err, err / ref_max);
+  if (AGG == 0 && REUSE == 1)
+    printf("%-22s %8.3f us/pass  %7.1f fp32-equivalent TFLOP/s  x%4.2f vs f32 MFMA   VGPRs %3d  max err %.3e (%.2e of range)\n",
+           name, ms / iters * 1e3, tf, base_ms[0] / (ms / iters), attr.numRegs, err, err / ref_max);
+  else
+    printf("%-22s %8.3f us/pass  %7.1f fp32-equivalent TFLOP/s  x%4.2f vs f32 MFMA   VGPRs %3d\n", name, ms / iters * 1e3, tf,
+           base_ms[0] / (ms / iters), attr.numRegs);
 }
 
 int main() {
@@ -217,5 +239,13 @@ int main() {
   run<1>("bf16x1", dW, dX, dY, ref, ref_max, blocks, base);
   run<3>("bf16x3", dW, dX, dY, ref, ref_max, blocks, base);
   run<6>("bf16x6", dW, dX, dY, ref, ref_max, blocks, base);
+  printf("B operand = two-entry aggregate (graph-conv unit):\n");
+  run<0, 1>("f32    + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
+  run<3, 1>("bf16x3 + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
+  run<6, 1>("bf16x6 + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
+  printf("one B operand, three A sets (temporal-conv taps):\n");
+  run<0, 0, 3>("f32    x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
+  run<3, 0, 3>("bf16x3 x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
+  run<6, 0, 3>("bf16x6 x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
   return 0;
 }
