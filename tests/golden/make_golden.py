@@ -19,7 +19,9 @@ tests/cases.py) and the reference's outputs.
       `farthest_point_sample` / `index_points` (net_utils/libs.py:152-190; random start
       patched to index 0) on the tie-free, origin-free clouds: reference-generated
       vectors for a1 / a2 (the CUDA kernel adds the |p|^2 <= 1e-3 skip and the block
-      tie rule, which these clouds do not exercise; margins recorded).
+      tie rule, which these clouds do not exercise; margins recorded).  Also: group_points forward
+      from `index_points` with a 3-D index, three_nn(x, x) index sets from `vn_dgcnn_util.knn`
+      (vn_dgcnn_util.py:4-10).
   G3-G5 are produced by tests/golden/make_model_golden.py (full model paths).
 """
 import os
@@ -251,6 +253,29 @@ def g6b():
             out["gather_" + key] = libs.index_points(feats.transpose(1, 2).contiguous(), cent).transpose(1, 2).contiguous().numpy()
     finally:
         torch.randint = real_randint
+    # a4 forward / a17 three_nn indices from two more pieces of reference-held torch code:
+    #   group_points(points (B,C,N), idx (B,P,S)) == libs.index_points on (B,N,C) rows with a 3-D index (libs.py:175-190);
+    #   three_nn(x, x) indices == vn_dgcnn_util.knn(x, 3) (vn_dgcnn_util.py:4-10: -|a|^2 + 2ab - |b|^2 and topk), for
+    #   clouds whose 3rd / 4th neighbour gap is > 64 ulps of the LARGEST squared norm involved (the expanded form cancels
+    #   at that scale), compared as index SETS per point (topk orders its ties with the point itself differently).
+    from net_utils import vn_dgcnn_util
+    for (b, n, p_, s_, c, seed) in [(2, 512, 128, 16, 7, 1), (1, 100, 9, 5, 3, 2), (3, 64, 64, 4, 1, 3)]:
+        g = torch.Generator().manual_seed(100 + seed)
+        pts = torch.randn(b, c, n, generator=g)
+        idx = torch.randint(0, n, (b, p_, s_), generator=g, dtype=torch.int64)
+        key = f"{b}_{n}_{p_}_{s_}_{c}_{seed}"
+        out["group_" + key] = libs.index_points(pts.transpose(1, 2).contiguous(), idx).permute(0, 3, 1, 2).contiguous().numpy()
+    for (b, n, kind, seed) in [(2, 64, "uniform", 1), (3, 48, "uniform", 2), (2, 100, "uniform", 4), (1, 32, "uniform", 5), (4, 24, "uniform", 6)]:
+        xyz = cases.cloud(b, n, seed, kind)
+        d2 = ((xyz[:, :, None, :].double() - xyz[:, None, :, :].double()) ** 2).sum(-1)
+        srt = d2.sort(-1)[0]
+        gap = ((srt[..., 3] - srt[..., 2]) / (xyz.double() ** 2).sum(-1).max()).min().item() / 2.0 ** -23
+        if not gap > 64.0:
+            continue
+        key = f"{b}_{n}_{kind}_{seed}"
+        out["knn3_" + key] = vn_dgcnn_util.knn(xyz.transpose(1, 2).contiguous(), 3).sort(-1)[0].numpy().astype(np.int32)
+        out["knn3gap_" + key] = np.array(gap)
+    assert len([k for k in out if k.startswith('knn3_')]) >= 2, sorted(out)
     assert len([k for k in out if k.startswith('fps_')]) >= 6, sorted(out)
     np.savez_compressed(os.path.join(HERE, "g6b_fps_ref.npz"), **out)
     print("g6b", sorted(k for k in out if k.startswith('gap_')), [float(out[k]) for k in sorted(out) if k.startswith('gap_')])

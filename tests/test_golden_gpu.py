@@ -76,3 +76,19 @@ def test_g6b_fps_and_gather_vs_reference_torch_code(dev):
         assert np.array_equal(_ext.gather_points(feats, idx).cpu().numpy(), z["gather_" + key]), key
         seen += 1
     assert seen >= 6
+
+
+def test_g6b_group_points_and_three_nn_vs_reference_torch_code(dev):
+    """HIP group_points / three_nn against vectors of the reference's `index_points` / `knn` (no oracle involved)."""
+    from pose2room_amd.pointnet2_ops import _ext
+    from tests.test_oracle_golden import _g6b_group_cases, _g6b_knn_cases
+    z = np.load(os.path.join(G, "g6b_fps_ref.npz"))
+    n_g = n_k = 0
+    for key, pts, idx in _g6b_group_cases(z):
+        assert np.array_equal(_ext.group_points(pts.to(dev), idx.to(dev)).cpu().numpy(), z["group_" + key]), key
+        n_g += 1
+    for key, xyz in _g6b_knn_cases(z):
+        _, i3 = _ext.three_nn(xyz.to(dev), xyz.to(dev))
+        assert np.array_equal(np.sort(i3.cpu().numpy(), -1), z["knn3_" + key]), key
+        n_k += 1
+    assert n_g >= 3 and n_k >= 2

@@ -92,6 +92,38 @@ def test_g6b_fps_and_gather_match_the_references_torch_code(oracle):
     assert seen >= 6
 
 
+def _g6b_group_cases(z):
+    for key in sorted(k[6:] for k in z.files if k.startswith("group_")):
+        b, n, p_, s_, c, seed = (int(v) for v in key.split("_"))
+        g = torch.Generator().manual_seed(100 + seed)
+        pts = torch.randn(b, c, n, generator=g)
+        idx = torch.randint(0, n, (b, p_, s_), generator=g, dtype=torch.int64)
+        yield key, pts, idx.int()
+
+
+def _g6b_knn_cases(z):
+    for key in sorted(k[5:] for k in z.files if k.startswith("knn3_")):
+        b, n, kind, seed = key.split("_")
+        yield key, cases.cloud(int(b), int(n), int(seed), kind)
+
+
+def test_g6b_group_points_and_three_nn_match_the_references_torch_code(oracle):
+    """a4 forward against `libs.index_points` with a 3-D index (libs.py:175-190); three_nn(x, x) index sets against
+    `vn_dgcnn_util.knn(x, 3)` (vn_dgcnn_util.py:4-10) on clouds with a recorded 3rd / 4th neighbour gap."""
+    z = np.load(os.path.join(G, "g6b_fps_ref.npz"))
+    E = oracle.OracleExt
+    n_g = n_k = 0
+    for key, pts, idx in _g6b_group_cases(z):
+        assert np.array_equal(E.group_points(pts, idx).numpy(), z["group_" + key]), key
+        n_g += 1
+    for key, xyz in _g6b_knn_cases(z):
+        assert float(z["knn3gap_" + key]) > 64.0
+        _, i3 = E.three_nn(xyz, xyz)
+        assert np.array_equal(np.sort(i3.numpy(), -1), z["knn3_" + key]), key
+        n_k += 1
+    assert n_g >= 3 and n_k >= 2
+
+
 # ---- independent definitions (property tests of the restatement) -------------
 
 def _fps_bruteforce(xyz, m):
