@@ -291,3 +291,23 @@ def test_graph_tables_other_skeletons_cpu():
     assert gcn_op.GraphTables(Graph().A).gen2                                # the P2RNet skeleton keeps its stream
     with pytest.raises(gcn_tables.StreamBudgetError):
         gcn_tables.deal_runs([1] * 25, 8, 7)
+
+
+def test_g10a_config1_forward_and_loss_cpu():
+    """BASELINE configs[1] at its full size (bs=8, T=512) on the CPU: our host model with the oracle ops behind it against
+    the vectors the imported reference produced at that size (G10, tests/golden/make_headline_golden.py) -- forward end
+    points and the ten losses at the north star's 1e-4, train-mode BatchNorm.  (The GPU twin, and configs[2] at bs=32,
+    T=1024, are in tests/test_headline_gpu.py.)"""
+    from oracle.cpu_backend import cpu_ops
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    from tests.test_headline_gpu import _check_forward_and_loss, _mixture_noise, G10
+    z = np.load(G10)
+    net, cfg = build('train', 512)
+    net.train()
+    assert abs(cases.state_checksum(net) - float(z['g10a_wsum'][0])) < 1e-6 * float(z['g10a_wsum'][0])
+    batch = make_batch(8, 512, seed=612)
+    with torch.no_grad(), cpu_ops():
+        ep = net(dict(batch), eps=_mixture_noise(8, torch.device('cpu')))
+        loss = net.loss(ep, batch)
+    m = _check_forward_and_loss(z, 'g10a', ep, loss, 1e-4, 1e-4)
+    print('g10a cpu vs reference:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in m.items()})
