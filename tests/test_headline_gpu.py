@@ -394,3 +394,48 @@ def test_g10e_eval_bn_step_vs_reference(dev):
     bad = {n: v for n, v in worst.items() if not v <= (tol if behind(n) else 2e-3)}
     assert not bad, bad
     assert max(v for n, v in worst.items() if behind(n)) <= tol
+
+
+def test_g10f_long_sequence_eval_vs_reference(dev, oracle):
+    """BASELINE configs[4]'s stress length through the EVALUATION path (test_epoch.py:18-46 on one batch): bs=2, T=2048,
+    `generate(data, eval=True)` -- network, prediction parsing, far-box filter, NMS on device, per-class lists -- the
+    loss dict of `Tester.test_step` and `APCalculator.compute_metrics()` at IoU 0.25 / 0.5, against the imported
+    reference's run (G10f).  End points 1e-4; keep mask by decisions (tests/test_eval_gpu.py); metrics equal."""
+    from tests.test_model_cpu import build
+    from tests.test_eval_gpu import _check_keep_masks, _far_box_margin
+    from pose2room_amd.net_utils.ap_helper import APCalculator
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(G10)
+    far = bool(int(z['g10f_remove_far_box']))
+    net, cfg = build('test', 2048, device=dev, remove_far_box=far)
+    net = net.to(dev).eval()
+    data = make_batch(2, 2048, seed=4096, device=dev)
+    with torch.no_grad():
+        ep, eval_dict, parsed = net.generate(data, eval=True)
+        loss = net.loss(ep, data)
+    assert np.array_equal(ep['seed_inds'].cpu().numpy(), z['g10f_seed_inds'])
+    assert np.array_equal(ep['aggregated_vote_inds'].cpu().numpy(), z['g10f_aggregated_vote_inds'])
+    worst = {}
+    for k in ('vote_xyz', 'aggregated_vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores'):
+        worst[k] = _relmax(ep[k].cpu().numpy(), z[f'g10f_{k}'])
+        assert worst[k] <= 1e-4, (k, worst[k])
+    for k, v in loss.items():
+        a, b = float(v), float(z[f'g10f_loss_{k}'])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    ne_r = ne_o = margin_r = None
+    if far:
+        ne_r, margin_r = _far_box_margin(cfg, data, z['g10f_center'], z['g10f_size'], z['g10f_heading'])
+        ne_o, _ = _far_box_margin(cfg, data, ep['center'].cpu(), ep['size'].cpu(), ep['heading'].cpu())
+    _check_keep_masks(oracle, 'generate at T=2048', cfg.eval_config['nms_iou'],
+                      (parsed['pred_corners_3d'], parsed['obj_prob']), (z['g10f_pred_corners_3d'], z['g10f_obj_prob']),
+                      eval_dict['pred_mask'], z['g10f_pred_mask'], ne_o, ne_r, margin_r)
+    assert [len(l) for l in eval_dict['batch_pred_map_cls']] == z['g10f_n_pred'].tolist()
+    for thr in (0.25, 0.5):
+        calc = APCalculator(thr, getattr(cfg.dataset_config, 'class2type', None), False, device=dev)
+        calc.step(eval_dict['batch_pred_map_cls'], eval_dict['batch_gt_map_cls'])
+        metrics = calc.compute_metrics()
+        keys = [str(k) for k in z[f'g10f_metric_keys_{int(thr * 100)}']]
+        assert sorted(metrics) == keys
+        got = np.array([float(metrics[k]) for k in keys])
+        np.testing.assert_allclose(got, z[f'g10f_metric_vals_{int(thr * 100)}'], rtol=1e-6, atol=1e-9, equal_nan=True)
+    print('g10f vs reference:', {k: f'{v:.2e}' for k, v in worst.items()})
