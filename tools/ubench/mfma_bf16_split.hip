@@ -22,6 +22,7 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int C = 64;          // channels: rows of W, reduction length
 constexpr int N = 512;         // columns of the tile
@@ -47,7 +48,18 @@ __device__ __forceinline__ void split2(const float (&x)[8], bf8 &p1, bf8 &p2) {
   }
 }
 
-// MODE 0: f32 MFMA; 1: bf16 single term; 3: 3-term split; 6: 6-term split
+__device__ __forceinline__ void splith(const float (&x)[8], h8 &p1, h8 &p2) {      // x = p1 + 2^-11 p2 (22 significand bits)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 a = (_Float16)x[i];
+    p1[i] = a; p2[i] = (_Float16)((x[i] - (float)a) * 2048.f);
+  }
+}
+
+// MODE 0: f32 MFMA; 1: bf16 single term; 3: 3-term split; 6: 6-term split;
+// MODE 13 / 14: fp16 TWO-part split with the residual scaled by 2^11 (fp16 has 11 significand bits: two parts carry 22 of
+//   fp32's 24; the scaling keeps the residual out of fp16's subnormals), terms W1 X1 | W1 X2' + W2' X1 (| W2' X2') in
+//   separate accumulators combined as hi + 2^-11 lo (+ 2^-22 lo2): 3 / 4 MFMAs per product and 4 bytes per element
 // AGG: the B operand is a two-entry aggregate c0 x(col) + c1 x(col') built with FMAs from two LDS gathers per value, like
 //      a (plane, joint) unit of the graph conv (average neighbour-list length 2.1) -- the split then follows the combine;
 // REUSE: the (split) B operand feeds REUSE sets of A operands (3 = the taps of the temporal conv, whose B operand is the
@@ -106,6 +118,56 @@ __global__ __launch_bounds__(NW * 64, 1) void kern(int iters, const float *__res
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m], 0, 0, 0);
       }
+      finish(t, acc);
+    }
+  } else if constexpr (MODE == 13 || MODE == 14) {
+    h8 a1[2][4], a2[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = W[(16 * m + r) * C + 32 * h + 8 * g + i];
+        splith(w, a1[h][m], a2[h][m]);
+      }
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      f4 hi[4], lo[4], l2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) hi[m] = lo[m] = l2[m] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float *xb = xs + (32 * h + 8 * g) * RS + 16 * (wave + NW * t) + r;
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] = xb[i * RS];
+          if constexpr (AGG) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fmaf(xb[i * RS + 16], 0.75f, x[i] * 1.25f);
+          }
+          h8 b1, b2;
+          splith(x, b1, b2);
+#pragma unroll
+          for (int u = 0; u < REUSE; ++u) {
+            if constexpr (MODE == 14) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) l2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[h][m], b2, l2[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h][m], b2, lo[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) lo[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[h][m], b1, lo[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) hi[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[h][m], b1, hi[m], 0, 0, 0);
+          }
+        }
+      }
+      f4 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = hi[m] + lo[m] * (1.f / 2048.f) + l2[m] * (1.f / 4194304.f);
       finish(t, acc);
     }
   } else {
@@ -239,13 +301,17 @@ int main() {
   run<1>("bf16x1", dW, dX, dY, ref, ref_max, blocks, base);
   run<3>("bf16x3", dW, dX, dY, ref, ref_max, blocks, base);
   run<6>("bf16x6", dW, dX, dY, ref, ref_max, blocks, base);
+  run<13>("f16x3 (2-part)", dW, dX, dY, ref, ref_max, blocks, base);
+  run<14>("f16x4 (2-part)", dW, dX, dY, ref, ref_max, blocks, base);
   printf("B operand = two-entry aggregate (graph-conv unit):\n");
   run<0, 1>("f32    + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
   run<3, 1>("bf16x3 + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
   run<6, 1>("bf16x6 + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
+  run<13, 1>("f16x3  + aggregate", dW, dX, dY, ref, ref_max, blocks, base);
   printf("one B operand, three A sets (temporal-conv taps):\n");
   run<0, 0, 3>("f32    x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
   run<3, 0, 3>("bf16x3 x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
   run<6, 0, 3>("bf16x6 x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
+  run<13, 0, 3>("f16x3  x 3 taps", dW, dX, dY, ref, ref_max, blocks, base);
   return 0;
 }
