@@ -12,7 +12,7 @@ from pose2room_amd import _lib
 from pose2room_amd.p2rnet import tconv_op
 
 dev = torch.device('cuda:0')
-VARIANT = os.environ.get('VARIANT', 'bf16')          # bf16: six-term split-bf16; f16: three-term scaled two-part fp16
+VARIANT = os.environ.get('VARIANT', 'bf16')          # bf16: six-term split-bf16; f16 (= f16f4), f16f8: three-term scaled two-part fp16, 4- / 8-frame tiles
 proto = ctypes.CDLL(os.path.join(ROOT, 'tools', 'ubench', f'libtconv_{VARIANT}_proto.so'))
 entry = getattr(proto, 'proto_tconv3b_forward' if VARIANT == 'bf16' else 'proto_tconv3h_forward')
 entry.restype = ctypes.c_int
@@ -49,7 +49,10 @@ def timed(fn, reps=20):
 
 
 g = torch.Generator().manual_seed(0)
+TILE = 8 if VARIANT.endswith('f8') else 4
 for N, T in ((2, 16), (3, 64), (1, 4), (32, 1024)):
+    if T % TILE:
+        continue
     x = torch.randn(N, 64, T, V, generator=g).to(dev)
     scale, shift = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
     bias = torch.randn(64, generator=g).to(dev)

@@ -34,11 +34,16 @@ typedef _Float16 bf8 __attribute__((ext_vector_type(8)));   // (name kept from t
 
 
 namespace {
-constexpr int F = 4, V = 53, C = 64, NW = 8;
+#ifndef PROTO_F
+#define PROTO_F 4
+#endif
+constexpr int F = PROTO_F, V = 53, C = 64, NW = 8;
 constexpr int OC = F * V;            // 212 output columns per tile
 constexpr int WC = (F + 2) * V;      // 318 window columns (frames t0-1 .. t0+4)
-constexpr int CP = 336;              // columns per 8-channel row in LDS (>= 14 * 16 + 2 * 53 = 330; 336 * 16 B = 21 * 256 B)
-constexpr int NT = (OC + 15) / 16;   // 14 column tiles
+constexpr int NT = (OC + 15) / 16;   // column tiles: 14 (F = 4) / 27 (F = 8)
+constexpr int CP = (NT * 16 + 2 * V + 15) / 16 * 16;   // columns per 8-channel row in LDS: 336 / 544 (x 16 B = a multiple of 256 B)
+constexpr int NTW = (NT + 1) / 2;    // column tiles per wave: 7 / 14
+constexpr int SC = (WC + 63) / 64;   // staged columns per thread: 5 / 9
 constexpr int BUF = 2 * 4 * CP * 8;  // fp16 elements per phase buffer (43,008 bytes)
 
 struct Params { int T, tiles_per_seq, total_tiles; };
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
 
   // ---- A operands: W[tap][16 mq + r][32 ph + 8 g + i], three bf16 planes, for the whole kernel -----------------------
   const int mq = wave & 3, nh = wave >> 2;
-  const int nt0 = 7 * nh;                            // column tiles nt0 .. nt0 + 6
+  const int nt0 = NTW * nh;                          // column tiles nt0 .. nt0 + NTW - 1 (those < NT)
   bf8 a[2][3][2];                                    // [phase][tap][part]
 #pragma unroll
   for (int ph = 0; ph < 2; ++ph)
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
 
   // ---- staging: wave = (8-channel group kg, half hc of its channels); lane = column; 5 columns x 4 channels per thread --
   const int kg = wave & 3, hc = wave >> 2;
-  float pre[5][4];
+  float pre[SC][4];
   auto issue_loads = [&](int tile, int ph) __attribute__((always_inline)) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * F;
 #pragma unroll
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float *>(x + ((size_t)seq * C + ch) * rs), 0, 4 * rs, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < SC; ++i) {
         // a column outside the channel row (frame -1 of the first tile, frame T of the last; a negative offset wraps to
         // a huge unsigned one) comes back as zero from the range check; columns >= 318 of the last round land in the
         // unused tail of the LDS row
@@ -111,8 +116,9 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
       for (int j = 0; j < 4; ++j) { sc[j] = scale[32 * ph + 8 * kg + 4 * hc + j]; sh[j] = shift[32 * ph + 8 * kg + 4 * hc + j]; }
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int c = lane + 64 * i;                   // < 320 <= CP
+    for (int i = 0; i < SC; ++i) {
+      const int c = lane + 64 * i;
+      if (c >= CP) continue;
       const int gc = (t0 - 1) * V + c;
       const bool in = c < WC && gc >= 0 && gc < rs;  // outside the sequence: the zero padding of the convolution
       typedef _Float16 bf4 __attribute__((ext_vector_type(4)));
@@ -130,8 +136,9 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
     }
   };
   // columns WC .. CP-1 of every row are read by the padding lanes of the last column tile: keep them finite
-  for (int e = tid; e < 2 * 2 * 4 * (CP - 320); e += NW * 64) {
-    const int row = e / (CP - 320), c = 320 + e % (CP - 320);
+  constexpr int C0 = SC * 64 < CP ? SC * 64 : CP;      // columns [C0, CP) are never staged
+  for (int e = tid; e < 2 * 2 * 4 * (CP - C0); e += NW * 64) {
+    const int row = e / (CP - C0 > 0 ? CP - C0 : 1), c = C0 + e % (CP - C0 > 0 ? CP - C0 : 1);
     *reinterpret_cast<bf8 *>(lds + ((size_t)row * CP + c) * 8) = bf8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 
@@ -157,9 +164,9 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
   for (; tile < p.total_tiles; tile = tile_of(++it)) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * F;
     const int ntile = tile_of(it + 1);
-    f4 hi[7], lo[7];
+    f4 hi[NTW], lo[NTW];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NTW; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { hi[i][q] = bias ? bias[16 * mq + 4 * g + q] : 0.f; lo[i][q] = 0.f; }
     }
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
 #define MF(acc, ap, bp) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ph][tp][ap], bp, acc, 0, 0, 0);
 #endif
 #pragma unroll
-      for (int i = 0; i < 6; i += 2) {                 // column tiles in pairs: two independent accumulator chains
+      for (int i = 0; i + 1 < NTW; i += 2) {           // column tiles in pairs: two independent accumulator chains
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
           const int c0 = 16 * (nt0 + i) + r + tp * V, c1 = c0 + 16;      // window column of the output column at this tap
@@ -195,11 +202,13 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
           MF(lo[i], 0, b2) MF(lo[i + 1], 0, d2) MF(hi[i], 0, b1) MF(hi[i + 1], 0, d1) MF(lo[i], 1, b1) MF(lo[i + 1], 1, d1)
         }
       }
+      if constexpr (NTW & 1) {
 #pragma unroll
-      for (int tp = 0; tp < 3; ++tp) {                 // the seventh tile
-        const int c0 = 16 * (nt0 + 6) + r + tp * V;
-        const bf8 b1 = bfrag(0, c0), b2 = bfrag(1, c0);
-        MF(lo[6], 0, b2) MF(hi[6], 0, b1) MF(lo[6], 1, b1)
+        for (int tp = 0; tp < 3; ++tp) {               // the odd tile
+          const int c0 = 16 * (nt0 + NTW - 1) + r + tp * V;
+          const bf8 b1 = bfrag(0, c0), b2 = bfrag(1, c0);
+          MF(lo[NTW - 1], 0, b2) MF(hi[NTW - 1], 0, b1) MF(lo[NTW - 1], 1, b1)
+        }
       }
 #undef MF
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tconv3b_kernel(Params p, const flo
     // D: row 4 g + q of the 16-row block, column r of the 16-column tile
     float *og = out + (size_t)seq * C * rs + (size_t)t0 * V;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < NTW; ++i) {
       const int col = 16 * (nt0 + i) + r;
       if (col >= OC) continue;
 #pragma unroll
