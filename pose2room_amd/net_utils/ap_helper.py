@@ -194,7 +194,10 @@ def parse_predictions(est_data, gt_data, config_dict, return_device=False):
 
 
 def parse_groundtruths(gt_data, config_dict):
-    """GT boxes -> corners (ap_helper.py:257-292); masked-out slots stay zero."""
+    """GT boxes -> corners (ap_helper.py:257-292); masked-out slots stay zero.
+    Returns HOST arrays: {'sem_cls_label' (B,G) int64 ndarray, 'gt_corners_3d' (B,G,8,3) float64 ndarray,
+    'box_label_mask' (B,G) ndarray} -- the reference keeps 'sem_cls_label' as the input tensor and calls `.item()` per
+    box downstream; here the three results cross PCIe in one transfer and `assembly_gt_map_cls` accepts either."""
     gt_center = gt_data['center_label'][:, :, 0:3].detach()
     gt_size = torch.exp(gt_data['size']).detach()
     gt_heading = torch.atan2(gt_data['heading'][..., 0], gt_data['heading'][..., 1]).detach()
