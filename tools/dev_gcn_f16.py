@@ -2,7 +2,7 @@
 the product) against the product's exact-fp32 gcn3 kernel and a float64 einsum: values, time.
 
     python tools/gen_gcn_pair_sched.py
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -I tools/ubench -o tools/ubench/libgcn3h_proto.so tools/ubench/gcn3h_proto.hip
+    hipcc -O3 -fno-slp-vectorize -DTRAIL_NOPS -std=c++17 -fPIC --offload-arch=gfx950 -shared -I tools/ubench -o tools/ubench/libgcn3h_proto.so tools/ubench/gcn3h_proto.hip
     python tools/dev_gcn_f16.py
 """
 import ctypes, math, os, sys
@@ -24,6 +24,10 @@ t = tables.on(dev)
 buf = (ctypes.c_int * 16)()
 npairs = proto.proto_gcn3h_pairs(buf)
 pairs = [(buf[2 * i], buf[2 * i + 1]) for i in range(npairs)]
+ncp = proto.proto_gcn3h_cpairs(None)
+cbuf = (ctypes.c_int * (2 * ncp))()
+proto.proto_gcn3h_cpairs(cbuf)
+cp_index = torch.tensor(list(cbuf), dtype=torch.long, device=dev).view(ncp, 2)
 print('plane pairs', pairs)
 
 
@@ -43,7 +47,7 @@ def pack_weights(W):
     for ph in range(4):
         for m in range(4):
             row = (16 * m + r)[:, None].expand(64, 8)
-            ch = (16 * ph + 8 * (kg & 1))[:, None] + i[None, :]
+            ch = (16 * ph + (kg & 1))[:, None] + 2 * i[None, :]
             half = (kg >> 1)[:, None].expand(64, 8)
             wt = Wsel[:, half, row, ch] * scale                              # (P, 64, 8)
             p1 = wt.half()
@@ -59,11 +63,11 @@ XS = float(os.environ.get("XS", "1"))
 
 
 def run_proto(x, Wp16, scale, coef1, bias):
-    coef1 = coef1 * XS
+    cp = (coef1 * XS).flatten()[cp_index].contiguous()          # (ncp, 2): plane a's / plane b's coefficient of an entry
     scale = scale * XS
     z = torch.empty_like(x)
     N, _, T, _ = x.shape
-    rc = proto.proto_gcn3h_forward(N, T, coef1.shape[0], _lib.ptr(x), _lib.ptr(Wp16), _lib.ptr(coef1), _lib.ptr(bias),
+    rc = proto.proto_gcn3h_forward(N, T, _lib.ptr(x), _lib.ptr(Wp16), _lib.ptr(cp), _lib.ptr(bias),
                                    ctypes.c_float(scale), _lib.ptr(z), _lib.current_stream(dev))
     assert rc == 0, rc
     return z

@@ -16,11 +16,19 @@
 #include <cstdint>
 
 #include "gcn3h_sched.inc"
+#ifdef ABL_NO_LOAD_A    // timing ablation: the A operands are loaded once
+#define ABL_LOAD_A 0
+#else
+#define ABL_LOAD_A 1
+#endif
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int V = 53, F = 16, CP = 16, NPH = 4, NW = 8, SLOTS = 7;
 constexpr int RS = F * V;            // 848
@@ -43,32 +51,69 @@ __device__ __forceinline__ void dma16(const float *base, int voff, float *lds_ds
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
-// 12 MFMAs of a unit.  Through the builtin, not an assembly block: the compiler's hazard recogniser has to see them -- an
-// in-flight v_mfma_f32_16x16x32_f16 still reads its A / B registers after it has issued, and the vector instructions
-// that build the NEXT unit's operands in the same registers right behind an opaque assembly block corrupted them
-// (measured: 0.2 of range wrong in a few joints; 16 trailing s_nop left 2e-5).  The fp32 16x16x4 form of gcn3 does not
-// show this (one-register operands).
+// 12 MFMAs of a unit as ONE assembly block that accumulates in place ("+v" pins a tile to its registers for the whole
+// kernel; through the builtin the compiler renames the accumulators along every chain and reconciles the eight wave
+// programs through scratch: 409-733 spilled registers).  What the compiler does not do for assembly: the leading s_nop
+// covers VALU write -> MFMA read; an in-flight v_mfma_f32_16x16x32_f16 still reads its four-register B operand after it
+// has issued, so the NEXT unit's split must not write the same registers right behind the block (measured with one
+// register set: 0.2 of range wrong in a few joints) -- the B parts alternate between two register sets by unit parity.
 __device__ __forceinline__ void mfma12(f32x4 (&acc)[4], const h8 (&a1)[4], const h8 (&a2)[4], const h8 &b1, const h8 &b2) {
+#ifdef ABL_NO_MFMA      // timing ablation: the operands stay live, no matrix instruction
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+               : "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(b1), "v"(b2));
+  return;
+#endif
+#ifdef MFMA_BUILTIN
 #pragma unroll
   for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[m], b2, acc[m], 0, 0, 0);
 #pragma unroll
   for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[m], b1, acc[m], 0, 0, 0);
 #pragma unroll
   for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[m], b1, acc[m], 0, 0, 0);
+  return;
+#endif
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %4, %13, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %13, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %6, %13, %2\n\tv_mfma_f32_16x16x32_f16 %3, %7, %13, %3\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %8, %12, %0\n\tv_mfma_f32_16x16x32_f16 %1, %9, %12, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %10, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %11, %12, %3\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %4, %12, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %12, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %6, %12, %2\n\tv_mfma_f32_16x16x32_f16 %3, %7, %12, %3"
+#ifdef TRAIL_NOPS
+      "\n\ts_nop 15\n\ts_nop 3"     // MFMA write -> a spill store reading the accumulator (the compiler does not know)
+#endif
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+      : "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(a2[0]), "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(b1), "v"(b2));
 }
 
-// one chunk of a unit's union list: x[i] (+)= sum_j c_j X[8 (g & 1) + i][frame r][joint of entry j],
-// c_j = plane a's coefficient in lanes 0-31, plane b's in lanes 32-63
-template <int FIRST, int NE, int O0, int A0, int B0, int O1, int A1, int B1, int O2, int A2, int B2>
-__device__ __forceinline__ void chunk(const char *xl, const char *cl, bool up, float (&x)[8]) {
-  constexpr int off[3] = {O0, O1, O2}, ia[3] = {A0, A1, A2}, ib[3] = {B0, B1, B2};
+// x = x1 + x2 for a pair of values: x1 by v_cvt_pk_f16_f32, x2 = fp16(x - x1) by v_fma_mix (fp32 arithmetic on the fp16
+// source, one instruction per value instead of convert back + subtract + convert)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &p, unsigned &r) {
+  const h2 ph = __builtin_convertvector(f2{x0, x1}, h2);
+  p = __builtin_bit_cast(unsigned, ph);
+#ifdef SPLIT_C
+  r = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{x0, x1} - __builtin_convertvector(ph, f2), h2));
+  return;
+#endif
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r) : "v"(x0), "v"(x1), "v"(p));
+}
+
+// one chunk of a unit's union list: x[i] (+)= sum_j c_j X[ch(i)][frame r][joint of entry j], the lane's channels
+// ch(i) = 2 i + (g & 1) of the slice (rows of odd and even channels sit 16 banks apart: the two 16-lane groups of a
+// 32-lane LDS access do not collide); c_j = the lane's half of entry E_j of the combined coefficient table (plane a's
+// value for lanes 0-31, plane b's for lanes 32-63, zero where the plane lacks the neighbour).
+template <int FIRST, int NE, int O0, int E0, int O1, int E1, int O2, int E2>
+__device__ __forceinline__ void chunk(const char *xl, const char *cpl, float (&x)[8]) {
+  constexpr int off[3] = {O0, O1, O2}, id[3] = {E0, E1, E2};
   float xv[3][8], c[3];
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xv[j][i] = *reinterpret_cast<const float *>(xl + off[j] + i * RS * 4);
-    const float ca = *reinterpret_cast<const float *>(cl + 4 * ia[j]), cb = *reinterpret_cast<const float *>(cl + 4 * ib[j]);
-    c[j] = up ? cb : ca;
+    for (int i = 0; i < 8; ++i) xv[j][i] = *reinterpret_cast<const float *>(xl + off[j] + i * (2 * RS * 4));
+    c[j] = *reinterpret_cast<const float *>(cpl + 8 * id[j]);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -79,35 +124,34 @@ __device__ __forceinline__ void chunk(const char *xl, const char *cl, bool up, f
   }
 }
 
-#define H3_VISIT(set, pair, next, wrap, piece)                                  \
-  {                                                                             \
-    load_a(aS[(set) ^ 1], next, (wrap) ? ((ph + 1) & (NPH - 1)) : ph);           \
-    if ((piece) >= 0 && copy) dma_piece(piece);                                 \
+#define H3_PIECE(piece) { if (copy) dma_piece(piece); }
+#define H3_VISIT(pair, piece)                          \
+  {                                                    \
+    if (ABL_LOAD_A) load_a(aS, pair, ph);              \
+    if ((piece) >= 0 && copy) dma_piece(piece);        \
   }
-#define H3_B(first, ne, o0, a0, b0, o1, a1, b1, o2, a2, b2) chunk<first, ne, o0, a0, b0, o1, a1, b1, o2, a2, b2>(xl, cl, up, xagg);
-// The split x = x1 + x2 has to see the aggregate as an fp32 VALUE.  Without the empty asm the compiler contracts
-// fp16(c * x) of a one-entry list into v_fma_mixlo_f16 (one rounding of the exact product) in one place and keeps
-// fp16(fp32(c * x)) in another; where fp32(c * x) falls exactly between two fp16 numbers the two disagree, x2 is taken
-// against the other neighbour and x1 + x2 is off by one fp16 ulp (measured: 4 of 7 M aggregates, 1.8e-5 of range).
-#define H3_M(set, slot)                                                                   \
+#ifdef ABL_NO_GATHER    // timing ablation: no LDS gathers, no multiply-adds
+#define H3_B(first, ne, o0, e0, o1, e1, o2, e2) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" : "+v"(xagg[i_])); }
+#else
+#define H3_B(first, ne, o0, e0, o1, e1, o2, e2) chunk<first, ne, o0, e0, o1, e1, o2, e2>(xl, cpl, xagg);
+#endif
+#define H3_S(par)                                                                         \
   {                                                                                       \
-    h8 b1_, b2_;                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                    \
-      float v_ = xagg[i_];                                                                \
-      asm volatile("" : "+v"(v_));   /* see the note on H3_M */                           \
-      const _Float16 p_ = (_Float16)v_;                                                   \
-      b1_[i_] = p_; b2_[i_] = (_Float16)(v_ - (float)p_);                                 \
-    }                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    mfma12(acc[slot], aS[set][0], aS[set][1], b1_, b2_);                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned p_[4], r_[4];                                                                \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) split2(xagg[2 * q_], xagg[2 * q_ + 1], p_[q_], r_[q_]); \
+    b1_[par] = __builtin_bit_cast(h8, u4{p_[0], p_[1], p_[2], p_[3]});                     \
+    b2_[par] = __builtin_bit_cast(h8, u4{r_[0], r_[1], r_[2], r_[3]});                     \
   }
-#define H3_END(parity, pieces, pair0)                                                     \
+#define H3_M(slot, par)                                       \
+  {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    mfma12(acc[slot], aS[0], aS[1], b1_[par], b2_[par]);      \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  }
+#define H3_END(pieces, pair0)                                                             \
   {                                                                                       \
     if (copy) { _Pragma("unroll") for (int i_ = pieces; i_ < PW; ++i_) dma_piece(i_); }   \
-    if (parity) {                                                                         \
-      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) aS[0][q_][m_] = aS[1][q_][m_]; \
-    }                                                                                     \
+    load_a(aS, pair0, (ph + 1) & (NPH - 1));                                              \
   }
 
 template <int WAVE>
@@ -115,16 +159,15 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
                                           const h8 *__restrict__ Wp, float *__restrict__ z) {
   constexpr int wave = WAVE;
   float *bias_l = lds + 2 * BUF;                       // [64][V]
-  float *coef_l = bias_l + 64 * V;                     // [ltot + 1][V] (last row zeros)
+  float *cp_l = bias_l + 64 * V;                       // [H3_NCP][2]: the combined coefficient table
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, r = lane & 15;
-  const bool up = lane >= 32;
   constexpr const int (&sj)[SLOTS] = slot_joints[WAVE];
   const size_t row_stride = (size_t)p.T * V;
-  const char *xl0 = reinterpret_cast<const char *>(lds + 8 * (g & 1) * RS + r * V);   // channels 8 (g & 1) .., frame r
-  unsigned cl_off = (unsigned)((coef_l - lds) * sizeof(float));
-  asm volatile("" : "+v"(cl_off));                     // opaque base: see stgcn_gcn3.hip
-  const char *cl = reinterpret_cast<const char *>(lds) + cl_off;
+  const char *xl0 = reinterpret_cast<const char *>(lds + (g & 1) * RS + r * V);   // channels 2 i + (g & 1), frame r
+  unsigned cp_off = (unsigned)((cp_l - lds) * sizeof(float)) + 4 * (lane >> 5);
+  asm volatile("" : "+v"(cp_off));                     // opaque base: see stgcn_gcn3.hip
+  const char *cpl = reinterpret_cast<const char *>(lds) + cp_off;
 
   int doff[PW];
 #pragma unroll
@@ -135,9 +178,10 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   }
 
   f32x4 acc[SLOTS][4];
-  h8 aS[2][2][4];                                      // [set][part][m]: [W_a | W_b] rows 16 m + r, this lane's 8 k values
+  h8 aS[2][4];                                         // [part][m]: [W_a | W_b] rows 16 m + r, this lane's 8 k values
   float xagg[8];
-  auto load_a = [&](h8 (&a)[2][4], int pair, int ph) {
+  h8 b1_[2], b2_[2];
+  auto load_a = [&](h8 (&a)[2][4], int pair, int ph) {   // one register set: see tools/gen_gcn_pair_sched.py
     // Wp[pair][ph][part][m][lane] (16 bytes each)
     const h8 *wp = Wp + ((size_t)(pair * NPH + ph) * 2 * 4) * 64 + lane;
 #pragma unroll
@@ -154,7 +198,7 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
     for (int i = 0; i < PW; ++i)
       if (doff[i] >= 0) dma16(xr, doff[i], lds + (i * NW + wave) * 256);
   }
-  load_a(aS[0], plane0[WAVE], 0);
+  load_a(aS, plane0[WAVE], 0);
 
   for (; tile < p.total_tiles; tile += gridDim.x) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * F;
@@ -195,7 +239,7 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
     // ---- epilogue: the tile leaves through LDS as whole rows (stgcn_gcn3.hip), scaled back by 2^-S -------------------
     {
       float *stg = lds + ((NPH - 1) & 1) * BUF;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // MFMA results -> VALU reads: not the compiler's business for assembly
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -225,15 +269,15 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   }
 }
 
-__global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, int ltot1, const float *__restrict__ x,
-                                                           const h8 *__restrict__ Wp, const float *__restrict__ coef,
+__global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float *__restrict__ x,
+                                                           const h8 *__restrict__ Wp, const float *__restrict__ cp,
                                                            const float *__restrict__ bias_cv, float *__restrict__ z) {
   extern __shared__ float lds[];
   float *bias_l = lds + 2 * BUF;
-  float *coef_l = bias_l + 64 * V;
+  float *cp_l = bias_l + 64 * V;
   const int tid = threadIdx.x;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
-  for (int e = tid; e < ltot1 * V; e += NW * 64) coef_l[e] = coef[e];
+  for (int e = tid; e < 2 * H3_NCP; e += NW * 64) cp_l[e] = cp[e];
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
     case 0: wave_main<0>(p, lds, x, Wp, z); break;
@@ -248,21 +292,22 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, int ltot1, 
 }
 }  // namespace
 
-// x (N,64,T,53) f32; Wp: fp16 A operands [pair][phase][part][m][lane][8] built by tools/dev_gcn_f16.py from 2^S W;
-// coef f32 [ltot + 1][53]: the column-form coefficient table + one row of zeros; bias_cv (64,53) or NULL; scale = 2^S.
-// T % 16 == 0, x / z 16-byte aligned.
-extern "C" int proto_gcn3h_forward(int N, int T, int ltot1, const float *x, const void *Wp, const float *coef,
+// x (N,64,T,53) f32; Wp: fp16 A operands [pair][phase][part][m][lane][8] built by tools/dev_gcn_f16.py from 2^S W (k index
+// 8 kg + i of a lane = channel 16 ph + 2 i + (kg & 1) of plane kg >> 1 of the pair); cp f32 [H3_NCP][2]: the combined
+// coefficient table (proto_gcn3h_cpairs says which two entries of the column-form table + zero row each line holds);
+// bias_cv (64,53) or NULL; scale = 2^S.  T % 16 == 0, x / z 16-byte aligned.
+extern "C" int proto_gcn3h_forward(int N, int T, const float *x, const void *Wp, const float *cp,
                                    const float *bias_cv, float scale, float *z, void *stream) {
-  if (N <= 0 || T <= 0 || T % F != 0 || ltot1 != H3_LTOT + 1) return 1;
+  if (N <= 0 || T <= 0 || T % F != 0) return 1;
   Params p;
   p.T = T; p.tiles_per_seq = T / F; p.total_tiles = N * p.tiles_per_seq;
   p.scale = scale; p.inv_scale = 1.f / scale;
   const int blocks = p.total_tiles < 256 ? p.total_tiles : 256;
-  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)ltot1 * V) * sizeof(float);
+  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)2 * H3_NCP) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gcn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gcn3h_kernel, dim3(blocks), dim3(NW * 64), lds, (hipStream_t)stream, p, ltot1, x,
-                     reinterpret_cast<const h8 *>(Wp), coef, bias_cv, z);
+  hipLaunchKernelGGL(gcn3h_kernel, dim3(blocks), dim3(NW * 64), lds, (hipStream_t)stream, p, x,
+                     reinterpret_cast<const h8 *>(Wp), cp, bias_cv, z);
   return (int)hipGetLastError();
 }
 
@@ -270,4 +315,12 @@ extern "C" int proto_gcn3h_pairs(int *out) {          // the plane pairs of the 
   constexpr int pr[H3_NPAIRS][2] = H3_PAIRS;
   for (int i = 0; i < H3_NPAIRS; ++i) { out[2 * i] = pr[i][0]; out[2 * i + 1] = pr[i][1]; }
   return H3_NPAIRS;
+}
+
+// the combined coefficient table's lines: indices (plane a's, plane b's) into the flattened [ltot + 1][53] column-form
+// table whose last row is zeros
+extern "C" int proto_gcn3h_cpairs(int *out) {
+  constexpr int cpv[2 * H3_NCP] = H3_CPAIRS;
+  if (out) for (int i = 0; i < 2 * H3_NCP; ++i) out[i] = cpv[i];
+  return H3_NCP;
 }
