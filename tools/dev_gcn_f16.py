@@ -24,11 +24,6 @@ t = tables.on(dev)
 buf = (ctypes.c_int * 16)()
 npairs = proto.proto_gcn3h_pairs(buf)
 pairs = [(buf[2 * i], buf[2 * i + 1]) for i in range(npairs)]
-ncp = proto.proto_gcn3h_cpairs(None)
-cbuf = (ctypes.c_int * (2 * ncp))()
-proto.proto_gcn3h_cpairs(cbuf)
-cp_index = torch.tensor(list(cbuf), dtype=torch.long, device=dev).view(ncp, 2)
-print('plane pairs', pairs)
 
 
 def pack_weights(W):
@@ -47,8 +42,8 @@ def pack_weights(W):
     for ph in range(4):
         for m in range(4):
             row = (16 * m + r)[:, None].expand(64, 8)
-            ch = (16 * ph + (kg & 1))[:, None] + 2 * i[None, :]
-            half = (kg >> 1)[:, None].expand(64, 8)
+            ch = (16 * ph + kg)[:, None] + 4 * (i & 3)[None, :]             # k = 8 kg + i: channel kg + 4 (i & 3) ...
+            half = (i >> 2)[None, :].expand(64, 8)                            # ... of plane a (i < 4) or b (i >= 4)
             wt = Wsel[:, half, row, ch] * scale                              # (P, 64, 8)
             p1 = wt.half()
             out[:, ph, 0, m] = p1
@@ -63,11 +58,11 @@ XS = float(os.environ.get("XS", "1"))
 
 
 def run_proto(x, Wp16, scale, coef1, bias):
-    cp = (coef1 * XS).flatten()[cp_index].contiguous()          # (ncp, 2): plane a's / plane b's coefficient of an entry
+    coef1 = (coef1 * XS).contiguous()
     scale = scale * XS
     z = torch.empty_like(x)
     N, _, T, _ = x.shape
-    rc = proto.proto_gcn3h_forward(N, T, _lib.ptr(x), _lib.ptr(Wp16), _lib.ptr(cp), _lib.ptr(bias),
+    rc = proto.proto_gcn3h_forward(N, T, coef1.shape[0], _lib.ptr(x), _lib.ptr(Wp16), _lib.ptr(coef1), _lib.ptr(bias),
                                    ctypes.c_float(scale), _lib.ptr(z), _lib.current_stream(dev))
     assert rc == 0, rc
     return z
@@ -85,7 +80,8 @@ def timed(fn, reps=10):
 
 
 g = torch.Generator().manual_seed(0)
-for N, T in ((2, 16), (3, 64), (32, 1024)):
+SIZES = ((32, 1024),) if os.environ.get('REPS') else ((2, 16), (3, 64), (32, 1024))     # REPS: under a profiler, the bench shape only
+for N, T in SIZES:
     x = torch.relu(torch.randn(N, 64, T, V, generator=g) + 0.3).to(dev)       # like a BatchNorm + ReLU output
     W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
     Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
@@ -110,3 +106,13 @@ for N, T in ((2, 16), (3, 64), (32, 1024)):
         tq = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, t['stream_c'], bias, tables, form=0))
         msg += f'; prototype {tp:.3f} ms, product (no statistics) {tq:.3f} ms  -> x{tq / tp:.2f}'
     print(msg, flush=True)
+    if os.environ.get("PROFILE") and N * T > 4096:
+        prof = torch.zeros(256, 8, 4, dtype=torch.int64, device=dev)
+        proto.proto_gcn3h_profile(ctypes.c_void_p(prof.data_ptr()))
+        run_proto(x, Wp16, scale, coef1, bias); torch.cuda.synchronize()
+        proto.proto_gcn3h_profile(None)
+        pm = prof.double().mean(0)                                 # (8 waves, 4)
+        tot = pm.sum(1)
+        print('profile (s_memtime ticks per wave, mean over the workgroups): wave  phase-start wait | bodies | to epilogue | epilogue')
+        for w in range(8):
+            print('   %d  %8.0f %8.0f %8.0f %8.0f   (%.0f %% / %.0f %% / %.0f %% / %.0f %%)' % ((w,) + tuple(pm[w].tolist()) + tuple((100 * pm[w] / tot[w]).tolist())))

@@ -4,13 +4,14 @@
 // pose2room_amd/csrc/stgcn_gcn3.hip (persistent workgroups of 8 straight-line wave programs, 16-frame tiles, four
 // 16-channel slices by LDS-DMA into two buffers, accumulators of up to 7 joints per wave in registers, staged whole-row
 // stores); what changes is the step:
-//   * a step = a (plane pair, output joint) unit.  Lane (g, r): frame r, 8 channels 8 (g & 1) + i of the slice; lanes
-//     0-31 build plane a's aggregate, lanes 32-63 plane b's, from the UNION of the two neighbour lists (same LDS offsets
-//     for both halves; the coefficient of an entry is plane a's or plane b's value, zero where the plane lacks it);
+//   * a step = a (plane pair, output joint) unit.  K index k = 8 kg + i of lane (kg, r): frame r, channel kg + 4 (i & 3) of
+//     the slice, plane a of the pair for i < 4, plane b for i >= 4 -- every lane walks BOTH neighbour lists with four
+//     channels each: LDS offsets and coefficient indices are immediates common to the wave, nobody multiplies by zero;
 //   * the aggregate is split into two fp16 parts x = x1 + x2 (x2 unscaled: its absolute error, 3e-8, is what counts
 //     behind a BatchNorm + ReLU), W comes pre-split from the host as 2^S W = w1 + w2: three MFMAs per row tile
 //     (w1 x2, w2 x1, w1 x1) into ONE accumulator at scale 2^S;
-//   * 253 units per tile and phase instead of 454, 12 MFMAs of 16 cycles each instead of 16 of 32.
+//   * 253 units per tile and phase instead of 454, 12 MFMAs of 16 cycles each instead of 16 of 32;
+//   * software pipeline: split(u), loads of unit u + 1, the 12 MFMAs of u, multiply-adds of u + 1.
 // Forward only, no statistics epilogue.  Schedule: tools/gen_gcn_pair_sched.py -> gcn3h_sched.inc.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -39,7 +40,7 @@ constexpr int PW = (PIECES + NW - 1) / NW;       // 7
 constexpr int slot_joints[NW][SLOTS] = H3_SLOT_JOINTS;
 constexpr int plane0[NW] = {H3_PLANE0_0, H3_PLANE0_1, H3_PLANE0_2, H3_PLANE0_3, H3_PLANE0_4, H3_PLANE0_5, H3_PLANE0_6, H3_PLANE0_7};
 
-struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; };
+struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; unsigned long long *prof; };
 
 __device__ __forceinline__ unsigned lds_addr(const float *p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
@@ -101,39 +102,39 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &p, unsigned
       : "=&v"(r) : "v"(x0), "v"(x1), "v"(p));
 }
 
-// one chunk of a unit's union list: x[i] (+)= sum_j c_j X[ch(i)][frame r][joint of entry j], the lane's channels
-// ch(i) = 2 i + (g & 1) of the slice (rows of odd and even channels sit 16 banks apart: the two 16-lane groups of a
-// 32-lane LDS access do not collide); c_j = the lane's half of entry E_j of the combined coefficient table (plane a's
-// value for lanes 0-31, plane b's for lanes 32-63, zero where the plane lacks the neighbour).
-template <int FIRST, int NE, int O0, int E0, int O1, int E1, int O2, int E2>
-__device__ __forceinline__ void chunk(const char *xl, const char *cpl, float (&x)[8]) {
-  constexpr int off[3] = {O0, O1, O2}, id[3] = {E0, E1, E2};
-  float xv[3][8], c[3];
+// A chunk of a unit's entry list.  Loads: xv[j][i] = X[channel kg + 4 i][frame r][joint of entry j] (rows of
+// neighbouring channels sit 16 banks apart: the two 16-lane groups of a 32-lane LDS access do not collide), c[j] = the
+// entry's coefficient (uniform address: a broadcast read).  Combine: entry j belongs to plane half h_j; f_j = first
+// entry of that half (multiply instead of multiply-add); ZERO bit h = the half has no entry in this unit.
+template <int NE, int O0, int C0, int O1, int C1, int O2, int C2, int O3, int C3>
+__device__ __forceinline__ void h3_gather(const char *xl, const char *cl, float (&xv)[4][4], float (&c)[4]) {
+  constexpr int off[4] = {O0, O1, O2, O3}, ci[4] = {C0, C1, C2, C3};
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xv[j][i] = *reinterpret_cast<const float *>(xl + off[j] + i * (2 * RS * 4));
-    c[j] = *reinterpret_cast<const float *>(cpl + 8 * id[j]);
+    for (int i = 0; i < 4; ++i) xv[j][i] = *reinterpret_cast<const float *>(xl + off[j] + i * (4 * RS * 4));
+    c[j] = *reinterpret_cast<const float *>(cl + 4 * ci[j]);
   }
+}
+template <int NE, int ZERO, int H0, int F0, int H1, int F1, int H2, int F2, int H3, int F3>
+__device__ __forceinline__ void h3_combine(const float (&xv)[4][4], const float (&c)[4], float (&x)[8]) {
+  constexpr int h[4] = {H0, H1, H2, H3}, f[4] = {F0, F1, F2, F3};
+  if (ZERO & 1) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; x[3] = 0.f; }
+  if (ZERO & 2) { x[4] = 0.f; x[5] = 0.f; x[6] = 0.f; x[7] = 0.f; }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float v = FIRST ? c[0] * xv[0][i] : fmaf(c[0], xv[0][i], x[i]);
+  for (int j = 0; j < NE; ++j)
 #pragma unroll
-    for (int j = 1; j < NE; ++j) v = fmaf(c[j], xv[j][i], v);
-    x[i] = v;
-  }
+    for (int i = 0; i < 4; ++i) x[4 * h[j] + i] = f[j] ? c[j] * xv[j][i] : fmaf(c[j], xv[j][i], x[4 * h[j] + i]);
 }
 
 #define H3_PIECE(piece) { if (copy) dma_piece(piece); }
-#define H3_VISIT(pair, piece)                          \
-  {                                                    \
-    if (ABL_LOAD_A) load_a(aS, pair, ph);              \
-    if ((piece) >= 0 && copy) dma_piece(piece);        \
-  }
+#define H3_VISIT(pair) { if (ABL_LOAD_A) load_a(aS, pair, ph); }
 #ifdef ABL_NO_GATHER    // timing ablation: no LDS gathers, no multiply-adds
-#define H3_B(first, ne, o0, e0, o1, e1, o2, e2) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" : "+v"(xagg[i_])); }
+#define H3_G(k, ne, o0, c0, o1, c1, o2, c2, o3, c3)
+#define H3_C(k, ne, zero, h0, f0, h1, f1, h2, f2, h3, f3) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" : "+v"(xagg[i_])); }
 #else
-#define H3_B(first, ne, o0, e0, o1, e1, o2, e2) chunk<first, ne, o0, e0, o1, e1, o2, e2>(xl, cpl, xagg);
+#define H3_G(k, ne, o0, c0, o1, c1, o2, c2, o3, c3) h3_gather<ne, o0, c0, o1, c1, o2, c2, o3, c3>(xl, cl, xv_[k], cf_[k]);
+#define H3_C(k, ne, zero, h0, f0, h1, f1, h2, f2, h3, f3) h3_combine<ne, zero, h0, f0, h1, f1, h2, f2, h3, f3>(xv_[k], cf_[k], xagg);
 #endif
 #define H3_S(par)                                                                         \
   {                                                                                       \
@@ -148,26 +149,60 @@ __device__ __forceinline__ void chunk(const char *xl, const char *cpl, float (&x
     mfma12(acc[slot], aS[0], aS[1], b1_[par], b2_[par]);      \
     __builtin_amdgcn_sched_barrier(0);                        \
   }
+// interleave mode (GEN_MODE=interleave): single instructions, placed by the generator between the MFMAs of the unit in
+// front and fenced (the compiler neither clusters the MFMAs nor hoists the vector work: sched_group_barrier patterns
+// were ignored here).  MFMAs through the builtin: the compiler sees every hazard.
+#define H3_F __builtin_amdgcn_sched_barrier(0);
+#define H3_MF(slot, par, term, m)                                                                                           \
+  acc[slot][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS[(term) == 1][m], (term) == 0 ? b2_[par] : b1_[par], acc[slot][m], 0, 0, 0);
+#define H3_GC(k, j, ci) cf_[k][j] = *reinterpret_cast<const float *>(cl + 4 * (ci));
+#define H3_GX(k, j, i, off) xv_[k][j][i] = *reinterpret_cast<const float *>(xl + (off) + (i) * (4 * RS * 4));
+#define H3_C1(k, j, i, h, f) xagg[4 * (h) + (i)] = (f) ? cf_[k][j] * xv_[k][j][i] : fmaf(cf_[k][j], xv_[k][j][i], xagg[4 * (h) + (i)]);
+#define H3_Z1(zero)                                                              \
+  {                                                                              \
+    if ((zero) & 1) { xagg[0] = 0.f; xagg[1] = 0.f; xagg[2] = 0.f; xagg[3] = 0.f; } \
+    if ((zero) & 2) { xagg[4] = 0.f; xagg[5] = 0.f; xagg[6] = 0.f; xagg[7] = 0.f; } \
+  }
+#define H3_S1(par, q)                                                            \
+  {                                                                              \
+    unsigned p_, r_;                                                             \
+    split2(xagg[2 * (q)], xagg[2 * (q) + 1], p_, r_);                            \
+    const h2 ph_ = __builtin_bit_cast(h2, p_), rh_ = __builtin_bit_cast(h2, r_); \
+    b1_[par][2 * (q)] = ph_.x; b1_[par][2 * (q) + 1] = ph_.y;                    \
+    b2_[par][2 * (q)] = rh_.x; b2_[par][2 * (q) + 1] = rh_.y;                    \
+  }
 #define H3_END(pieces, pair0)                                                             \
   {                                                                                       \
     if (copy) { _Pragma("unroll") for (int i_ = pieces; i_ < PW; ++i_) dma_piece(i_); }   \
     load_a(aS, pair0, (ph + 1) & (NPH - 1));                                              \
   }
 
+// -DPROFILE: s_memtime stamps of every wave's lane 0 -> prof[block][wave][4] = cycles (waiting at the phase start,
+// phase bodies, between the last body and the epilogue, epilogue)
+#ifdef PROFILE
+#define PROF_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    if (i == 1) pw_ += t_ - tl_; if (i == 2) pb_ += t_ - tl_; if (i == 3) pg_ += t_ - tl_; if (i == 4) pe_ += t_ - tl_; tl_ = t_; }
+#define PROF_OUT { if (lane == 0 && p.prof) { unsigned long long *o_ = p.prof + ((size_t)blockIdx.x * NW + WAVE) * 4; \
+    o_[0] = pw_; o_[1] = pb_; o_[2] = pg_; o_[3] = pe_; } }
+#else
+#define PROF_T(i)
+#define PROF_OUT
+#endif
+
 template <int WAVE>
 __device__ __forceinline__ void wave_main(const Params &p, float *lds, const float *__restrict__ x,
                                           const h8 *__restrict__ Wp, float *__restrict__ z) {
   constexpr int wave = WAVE;
   float *bias_l = lds + 2 * BUF;                       // [64][V]
-  float *cp_l = bias_l + 64 * V;                       // [H3_NCP][2]: the combined coefficient table
+  float *coef_l = bias_l + 64 * V;                     // [ltot + 1][V] (last row zeros)
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, r = lane & 15;
   constexpr const int (&sj)[SLOTS] = slot_joints[WAVE];
   const size_t row_stride = (size_t)p.T * V;
-  const char *xl0 = reinterpret_cast<const char *>(lds + (g & 1) * RS + r * V);   // channels 2 i + (g & 1), frame r
-  unsigned cp_off = (unsigned)((cp_l - lds) * sizeof(float)) + 4 * (lane >> 5);
-  asm volatile("" : "+v"(cp_off));                     // opaque base: see stgcn_gcn3.hip
-  const char *cpl = reinterpret_cast<const char *>(lds) + cp_off;
+  const char *xl0 = reinterpret_cast<const char *>(lds + g * RS + r * V);   // channels g + 4 i, frame r
+  unsigned cl_off = (unsigned)((coef_l - lds) * sizeof(float));
+  asm volatile("" : "+v"(cl_off));                     // opaque base: see stgcn_gcn3.hip
+  const char *cl = reinterpret_cast<const char *>(lds) + cl_off;
 
   int doff[PW];
 #pragma unroll
@@ -177,9 +212,12 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
     doff[i] = (pc < PIECES && e < NV4) ? (int)(((size_t)row * row_stride + 4 * c4) * sizeof(float)) : -1;
   }
 
+#ifdef PROFILE
+  unsigned long long tl_ = __builtin_readcyclecounter(), pw_ = 0, pb_ = 0, pg_ = 0, pe_ = 0;
+#endif
   f32x4 acc[SLOTS][4];
   h8 aS[2][4];                                         // [part][m]: [W_a | W_b] rows 16 m + r, this lane's 8 k values
-  float xagg[8];
+  float xagg[8], xv_[5][4][4], cf_[5][4];
   h8 b1_[2], b2_[2];
   auto load_a = [&](h8 (&a)[2][4], int pair, int ph) {   // one register set: see tools/gen_gcn_pair_sched.py
     // Wp[pair][ph][part][m][lane] (16 bytes each)
@@ -221,8 +259,10 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
 
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
+      PROF_T(0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      PROF_T(1)
       float *buf_nxt = lds + ((ph + 1) & 1) * BUF;
       const char *xl = xl0 + (ph & 1) * BUF * sizeof(float);
       const bool copy = ph + 1 < NPH || has_next;
@@ -234,8 +274,10 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
       else if constexpr (WAVE == 2) { H3_BODY_2 } else if constexpr (WAVE == 3) { H3_BODY_3 }
       else if constexpr (WAVE == 4) { H3_BODY_4 } else if constexpr (WAVE == 5) { H3_BODY_5 }
       else if constexpr (WAVE == 6) { H3_BODY_6 } else { H3_BODY_7 }
+      PROF_T(2)
     }
 
+    PROF_T(3)
     // ---- epilogue: the tile leaves through LDS as whole rows (stgcn_gcn3.hip), scaled back by 2^-S -------------------
     {
       float *stg = lds + ((NPH - 1) & 1) * BUF;
@@ -266,18 +308,20 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
         __builtin_amdgcn_s_barrier();
       }
     }
+    PROF_T(4)
   }
+  PROF_OUT
 }
 
 __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float *__restrict__ x,
-                                                           const h8 *__restrict__ Wp, const float *__restrict__ cp,
+                                                           const h8 *__restrict__ Wp, const float *__restrict__ coef,
                                                            const float *__restrict__ bias_cv, float *__restrict__ z) {
   extern __shared__ float lds[];
   float *bias_l = lds + 2 * BUF;
-  float *cp_l = bias_l + 64 * V;
+  float *coef_l = bias_l + 64 * V;
   const int tid = threadIdx.x;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
-  for (int e = tid; e < 2 * H3_NCP; e += NW * 64) cp_l[e] = cp[e];
+  for (int e = tid; e < (H3_LTOT + 1) * V; e += NW * 64) coef_l[e] = coef[e];
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
     case 0: wave_main<0>(p, lds, x, Wp, z); break;
@@ -293,21 +337,24 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float
 }  // namespace
 
 // x (N,64,T,53) f32; Wp: fp16 A operands [pair][phase][part][m][lane][8] built by tools/dev_gcn_f16.py from 2^S W (k index
-// 8 kg + i of a lane = channel 16 ph + 2 i + (kg & 1) of plane kg >> 1 of the pair); cp f32 [H3_NCP][2]: the combined
-// coefficient table (proto_gcn3h_cpairs says which two entries of the column-form table + zero row each line holds);
-// bias_cv (64,53) or NULL; scale = 2^S.  T % 16 == 0, x / z 16-byte aligned.
-extern "C" int proto_gcn3h_forward(int N, int T, const float *x, const void *Wp, const float *cp,
+// 8 kg + i of a lane = channel 16 ph + kg + 4 (i & 3), plane a of the pair for i < 4, plane b for i >= 4); coef f32
+// [ltot + 1][53]: the column-form coefficient table + one row of zeros; bias_cv (64,53) or NULL; scale = 2^S.
+// T % 16 == 0, x / z 16-byte aligned.
+static unsigned long long *g_prof = nullptr;
+extern "C" void proto_gcn3h_profile(void *buf) { g_prof = reinterpret_cast<unsigned long long *>(buf); }   // [256][8][4] u64, -DPROFILE
+
+extern "C" int proto_gcn3h_forward(int N, int T, int ltot1, const float *x, const void *Wp, const float *coef,
                                    const float *bias_cv, float scale, float *z, void *stream) {
-  if (N <= 0 || T <= 0 || T % F != 0) return 1;
+  if (N <= 0 || T <= 0 || T % F != 0 || ltot1 != H3_LTOT + 1) return 1;
   Params p;
   p.T = T; p.tiles_per_seq = T / F; p.total_tiles = N * p.tiles_per_seq;
-  p.scale = scale; p.inv_scale = 1.f / scale;
+  p.scale = scale; p.inv_scale = 1.f / scale; p.prof = g_prof;
   const int blocks = p.total_tiles < 256 ? p.total_tiles : 256;
-  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)2 * H3_NCP) * sizeof(float);
+  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)ltot1 * V) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gcn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gcn3h_kernel, dim3(blocks), dim3(NW * 64), lds, (hipStream_t)stream, p, x,
-                     reinterpret_cast<const h8 *>(Wp), cp, bias_cv, z);
+                     reinterpret_cast<const h8 *>(Wp), coef, bias_cv, z);
   return (int)hipGetLastError();
 }
 
@@ -315,12 +362,4 @@ extern "C" int proto_gcn3h_pairs(int *out) {          // the plane pairs of the 
   constexpr int pr[H3_NPAIRS][2] = H3_PAIRS;
   for (int i = 0; i < H3_NPAIRS; ++i) { out[2 * i] = pr[i][0]; out[2 * i + 1] = pr[i][1]; }
   return H3_NPAIRS;
-}
-
-// the combined coefficient table's lines: indices (plane a's, plane b's) into the flattened [ltot + 1][53] column-form
-// table whose last row is zeros
-extern "C" int proto_gcn3h_cpairs(int *out) {
-  constexpr int cpv[2 * H3_NCP] = H3_CPAIRS;
-  if (out) for (int i = 0; i < 2 * H3_NCP; ++i) out[i] = cpv[i];
-  return H3_NCP;
 }
