@@ -15,7 +15,8 @@ from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
 from pose2room_amd.p2rnet import gcn_op, gcn_tables
 
 dev = torch.device('cuda:0')
-proto = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", os.environ.get("PROTO_LIB", "libgcn3h_proto.so")))
+FORM = os.environ.get("FORM", "c")      # "c": forward; "r": data gradient (libgcn3h_proto_r.so, built with -DH3_FORM_R from gcn3h_sched_r.inc)
+proto = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", os.environ.get("PROTO_LIB", "libgcn3h_proto_r.so" if FORM == "r" else "libgcn3h_proto.so")))
 proto.proto_gcn3h_forward.restype = ctypes.c_int
 A = Graph().A
 K, V = A.shape[0], A.shape[1]
@@ -51,7 +52,7 @@ def pack_weights(W):
     return out.contiguous(), scale
 
 
-XS = float(os.environ.get("XS", "1"))
+XS = float(os.environ.get("XS", "1"))     # (FORM=r sets it from the gradient's magnitude)
 # Optional power-of-two pre-scale of the aggregate (carried by the coefficient table, undone by `scale`).  Kept as a knob
 # because the fp16 residual x - fp16(x) of a small activation is a SUBNORMAL fp16 number; measured on gfx950 the error is
 # the same at XS = 1, 32 and 1024 (9.3e-7 / 1.0e-6 of range), i.e. v_mfma_f32_16x16x32_f16 does not flush them.
@@ -82,28 +83,42 @@ def timed(fn, reps=10):
 g = torch.Generator().manual_seed(0)
 SIZES = ((32, 1024),) if os.environ.get('REPS') else ((2, 16), (3, 64), (32, 1024))     # REPS: under a profiler, the bench shape only
 for N, T in SIZES:
-    x = torch.relu(torch.randn(N, 64, T, V, generator=g) + 0.3).to(dev)       # like a BatchNorm + ReLU output
     W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
     Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
-    bias = torch.randn(64, V, generator=g).to(dev)
-    cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    if FORM == "r":
+        # dX = sum_k W_k^T (dZ . A_k^T): the same kernel over the row lists with the transposed weights; the input is a
+        # GRADIENT (here ~1e-4): the coefficient table carries a power of two that lifts the aggregate into fp16's range
+        x = (torch.randn(N, 64, T, V, generator=g) * 1e-4).to(dev)
+        bias = torch.zeros(64, V, device=dev)
+        cc = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+        Wk = W.transpose(1, 2).contiguous()                                       # [k][ci][c]
+        XS = 2.0 ** round(math.log2(256.0 / float(x.abs().max())))
+        stream, form = t['stream_r'], 1
+        sub = 'nctw,kvw->nkctv'
+    else:
+        x = torch.relu(torch.randn(N, 64, T, V, generator=g) + 0.3).to(dev)       # like a BatchNorm + ReLU output
+        bias = torch.randn(64, V, generator=g).to(dev)
+        cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+        Wk = W
+        stream, form = t['stream_c'], 0
+        sub = 'nctv,kvw->nkctw'
     coef1 = torch.cat([cc, torch.zeros(1, V, device=dev)]).contiguous()
-    Wp16, scale = pack_weights(W)
+    Wp16, scale = pack_weights(Wk)
     got = run_proto(x, Wp16, scale, coef1, bias)
-    Wp = gcn_op.permute_planes(W)
-    prod = gcn_op._gcn2_forward(x, Wp, cc, t['stream_c'], bias, tables, form=0)
+    Wp = gcn_op.permute_planes(Wk)
+    prod = gcn_op._gcn2_forward(x, Wp, cc, stream, bias if FORM != "r" else None, tables, form=form)
     prod = prod[0] if isinstance(prod, tuple) else prod
-    msg = f'N={N} T={T}: '
+    msg = f'{"data gradient" if FORM == "r" else "forward"} N={N} T={T}: '
     if N * T <= 4096:
-        U = torch.einsum('nctv,kvw->nkctw', x.double(), Aeff.double())
-        ref = torch.einsum('kdc,nkctw->ndtw', W.double(), U) + bias.double()[None, :, None, :]
+        U = torch.einsum(sub, x.double(), Aeff.double())
+        ref = torch.einsum('kdc,nkctw->ndtw', Wk.double(), U) + bias.double()[None, :, None, :]
         rng = ref.abs().max().item()
         msg += (f'prototype vs fp64 {((got.double() - ref).abs().max().item() / rng):.2e} of range, '
                 f'product (fp32 MFMA) vs fp64 {((prod.double() - ref).abs().max().item() / rng):.2e}')
     else:
         msg += f'prototype vs product {((got - prod).abs().max().item() / prod.abs().max().item()):.2e} of range'
         tp = timed(lambda: run_proto(x, Wp16, scale, coef1, bias))
-        tq = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, t['stream_c'], bias, tables, form=0))
+        tq = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, stream, bias if FORM != "r" else None, tables, form=form))
         msg += f'; prototype {tp:.3f} ms, product (no statistics) {tq:.3f} ms  -> x{tq / tp:.2f}'
     print(msg, flush=True)
     if os.environ.get("PROFILE") and N * T > 4096:

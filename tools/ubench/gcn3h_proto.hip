@@ -16,7 +16,11 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#ifdef H3_FORM_R      // the data gradient: row lists, W_k^T (same kernel, other schedule)
+#include "gcn3h_sched_r.inc"
+#else
 #include "gcn3h_sched.inc"
+#endif
 #ifdef ABL_NO_LOAD_A    // timing ablation: the A operands are loaded once
 #define ABL_LOAD_A 0
 #else
