@@ -175,6 +175,21 @@ __device__ __forceinline__ void h3_combine(const float (&xv)[4][4], const float 
     b1_[par][2 * (q)] = ph_.x; b1_[par][2 * (q) + 1] = ph_.y;                    \
     b2_[par][2 * (q)] = rh_.x; b2_[par][2 * (q) + 1] = rh_.y;                    \
   }
+#define H3_M2(slot, par, set)                                 \
+  {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    mfma12(acc[slot], aS2[set][0], aS2[set][1], b1_[par], b2_[par]); \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  }
+#define H3_VISIT2(set, pair, wrap) { load_a(aS2[set], pair, (wrap) ? ((ph + 1) & (NPH - 1)) : ph); }
+// two A register sets by visit parity; a phase with an odd number of visits leaves the next phase's first set in [1]
+#define H3_END2(pieces, parity)                                                           \
+  {                                                                                       \
+    if (copy) { _Pragma("unroll") for (int i_ = pieces; i_ < PW; ++i_) dma_piece(i_); }   \
+    if (parity) {                                                                         \
+      _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) aS2[0][q_][m_] = aS2[1][q_][m_]; \
+    }                                                                                     \
+  }
 #define H3_END(pieces, pair0)                                                             \
   {                                                                                       \
     if (copy) { _Pragma("unroll") for (int i_ = pieces; i_ < PW; ++i_) dma_piece(i_); }   \
@@ -220,7 +235,12 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   unsigned long long tl_ = __builtin_readcyclecounter(), pw_ = 0, pb_ = 0, pg_ = 0, pe_ = 0;
 #endif
   f32x4 acc[SLOTS][4];
+#if H3_ASETS == 2
+  h8 aS2[2][2][4];                                     // [set][part][m]
+  h8 (&aS)[2][4] = aS2[0];
+#else
   h8 aS[2][4];                                         // [part][m]: [W_a | W_b] rows 16 m + r, this lane's 8 k values
+#endif
   float xagg[8], xv_[5][4][4], cf_[5][4];
   h8 b1_[2], b2_[2];
   auto load_a = [&](h8 (&a)[2][4], int pair, int ph) {   // one register set: see tools/gen_gcn_pair_sched.py
