@@ -21,6 +21,11 @@
 #else
 #include "gcn3h_sched.inc"
 #endif
+#ifdef ABL_NO_SPLIT     // timing ablation: the aggregate's bits go to the MFMAs unsplit
+#define ABL_SPLIT 0
+#else
+#define ABL_SPLIT 1
+#endif
 #ifdef ABL_NO_LOAD_A    // timing ablation: the A operands are loaded once
 #define ABL_LOAD_A 0
 #else
@@ -143,7 +148,10 @@ __device__ __forceinline__ void h3_combine(const float (&xv)[4][4], const float 
 #define H3_S(par)                                                                         \
   {                                                                                       \
     unsigned p_[4], r_[4];                                                                \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) split2(xagg[2 * q_], xagg[2 * q_ + 1], p_[q_], r_[q_]); \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                    \
+      if (ABL_SPLIT) split2(xagg[2 * q_], xagg[2 * q_ + 1], p_[q_], r_[q_]);             \
+      else { p_[q_] = __builtin_bit_cast(unsigned, xagg[2 * q_]); r_[q_] = __builtin_bit_cast(unsigned, xagg[2 * q_ + 1]); } \
+    }                                                                                     \
     b1_[par] = __builtin_bit_cast(h8, u4{p_[0], p_[1], p_[2], p_[3]});                     \
     b2_[par] = __builtin_bit_cast(h8, u4{r_[0], r_[1], r_[2], r_[3]});                     \
   }
@@ -302,6 +310,7 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
     }
 
     PROF_T(3)
+#ifndef ABL_NO_EPI      // (timing ablation: no staged stores)
     // ---- epilogue: the tile leaves through LDS as whole rows (stgcn_gcn3.hip), scaled back by 2^-S -------------------
     {
       float *stg = lds + ((NPH - 1) & 1) * BUF;
@@ -332,6 +341,9 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
         __builtin_amdgcn_s_barrier();
       }
     }
+#else
+    { _Pragma("unroll") for (int i = 0; i < SLOTS; ++i) _Pragma("unroll") for (int m = 0; m < 4; ++m) asm volatile("" :: "v"(acc[i][m])); }
+#endif
     PROF_T(4)
   }
   PROF_OUT
