@@ -12,7 +12,8 @@ from pose2room_amd import _lib
 from pose2room_amd.p2rnet import tconv_op
 
 dev = torch.device('cuda:0')
-VARIANT = os.environ.get('VARIANT', 'bf16')          # bf16: six-term split-bf16; f16 (= f16f4), f16f8: three-term scaled two-part fp16, 4- / 8-frame tiles
+VARIANT = os.environ.get('VARIANT', 'bf16')          # bf16: six-term split-bf16; f16 (= f16f4), f16f8: three-term scaled two-part fp16, 4- / 8-frame tiles;
+#                                                      f16w: the walking design (tconv_f16w_proto.hip), T % 64 == 0
 proto = ctypes.CDLL(os.path.join(ROOT, 'tools', 'ubench', f'libtconv_{VARIANT}_proto.so'))
 entry = getattr(proto, 'proto_tconv3b_forward' if VARIANT == 'bf16' else 'proto_tconv3h_forward')
 entry.restype = ctypes.c_int
@@ -49,11 +50,13 @@ def timed(fn, reps=20):
 
 
 g = torch.Generator().manual_seed(0)
-TILE = 8 if VARIANT.endswith('f8') else 4
+TILE = 64 if VARIANT.startswith('f16w') else (8 if VARIANT.endswith('f8') else 4)
 for N, T in ((2, 16), (3, 64), (1, 4), (32, 1024)):
     if T % TILE:
         continue
-    x = torch.randn(N, 64, T, V, generator=g).to(dev)
+    xbuf = torch.zeros(N * 64 * T * V + 64, device=dev)          # (f16w's last 8-float loads reach past joint 52)
+    x = xbuf[:N * 64 * T * V].view(N, 64, T, V)
+    x.copy_(torch.randn(N, 64, T, V, generator=g))
     scale, shift = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
     bias = torch.randn(64, generator=g).to(dev)
     W = (torch.randn(3, 64, 64, generator=g) / 8).to(dev)
