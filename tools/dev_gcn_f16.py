@@ -121,6 +121,34 @@ for N, T in SIZES:
         tq = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, stream, bias if FORM != "r" else None, tables, form=form))
         msg += f'; prototype {tp:.3f} ms, product (no statistics) {tq:.3f} ms  -> x{tq / tp:.2f}'
     print(msg, flush=True)
+    if FORM != "r":
+        # the statistics epilogue: per-workgroup (count, mean, M2) per channel, merged (Chan) and compared with the
+        # moments of the stored tensor and with what the product's gcn3 epilogue reports
+        def merge(part):
+            part = part.double()
+            n, mean, m2 = part[:, :, 0], part[:, :, 1], part[:, :, 2]
+            ntot = n.sum(0)
+            mu = (n * mean).sum(0) / ntot
+            return mu, (m2 + n * (mean - mu) ** 2).sum(0) / ntot
+        nblk = min(N * (T // 16), 256)
+        spart = torch.zeros(nblk, 64, 3, device=dev)
+        proto.proto_gcn3h_stats(ctypes.c_void_p(spart.data_ptr()))
+        got2 = run_proto(x, Wp16, scale, coef1, bias); torch.cuda.synchronize()
+        if N * T > 4096:
+            ts = timed(lambda: run_proto(x, Wp16, scale, coef1, bias))
+            tqs = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, stream, bias, tables, want_stats=True, form=0))
+            print(f'   with the statistics epilogue: prototype {ts:.3f} ms, product {tqs:.3f} ms -> x{tqs / ts:.2f}')
+        proto.proto_gcn3h_stats(None)
+        mu, var = merge(spart)
+        g64 = got2.double()
+        mu_t, var_t = g64.mean(dim=(0, 2, 3)), g64.var(dim=(0, 2, 3), unbiased=False)
+        zp, ppart = gcn_op._gcn2_forward(x, Wp, cc, stream, bias, tables, want_stats=True, form=0)
+        mu_p, var_p = merge(ppart.view(-1, 64, 3))
+        print(f'   statistics epilogue: mean {((mu - mu_t).abs().max() / mu_t.abs().max()).item():.1e}, variance '
+              f'{((var - var_t).abs() / var_t).max().item():.1e} (relative, vs the stored tensor in float64); product epilogue vs its '
+              f'tensor: {((mu_p - zp.double().mean(dim=(0, 2, 3))).abs().max() / mu_t.abs().max()).item():.1e}, '
+              f'{((var_p - zp.double().var(dim=(0, 2, 3), unbiased=False)).abs() / var_t).max().item():.1e}; outputs equal with / without: '
+              f'{bool(torch.equal(got, got2))}', flush=True)
     if os.environ.get("PROFILE") and N * T > 4096:
         prof = torch.zeros(256, 8, 4, dtype=torch.int64, device=dev)
         proto.proto_gcn3h_profile(ctypes.c_void_p(prof.data_ptr()))

@@ -49,7 +49,7 @@ constexpr int PW = (PIECES + NW - 1) / NW;       // 7
 constexpr int slot_joints[NW][SLOTS] = H3_SLOT_JOINTS;
 constexpr int plane0[NW] = {H3_PLANE0_0, H3_PLANE0_1, H3_PLANE0_2, H3_PLANE0_3, H3_PLANE0_4, H3_PLANE0_5, H3_PLANE0_6, H3_PLANE0_7};
 
-struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; unsigned long long *prof; };
+struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; unsigned long long *prof; float *stats; };
 
 __device__ __forceinline__ unsigned lds_addr(const float *p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
@@ -60,6 +60,16 @@ __device__ __forceinline__ void dma16(const float *base, int voff, float *lds_ds
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
+
+// Sum of v over the 16 lanes of a DPP row (csrc/p2r_common.h)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v;
+}
+constexpr int ST = 3;      // floats per (wave, row) statistics entry: (sum, sum of squares) about the pivot, pivot -- at the accumulators' scale
 
 // 12 MFMAs of a unit as ONE assembly block that accumulates in place ("+v" pins a tile to its registers for the whole
 // kernel; through the builtin the compiler renames the accumulators along every chain and reconciles the eight wave
@@ -222,6 +232,7 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   constexpr int wave = WAVE;
   float *bias_l = lds + 2 * BUF;                       // [64][V]
   float *coef_l = bias_l + 64 * V;                     // [ltot + 1][V] (last row zeros)
+  float *rowstat = coef_l + (H3_LTOT + 1) * V;         // [NW][64][ST]
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, r = lane & 15;
   constexpr const int (&sj)[SLOTS] = slot_joints[WAVE];
@@ -309,6 +320,36 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
       PROF_T(2)
     }
 
+    // statistics of the stored values for the BatchNorm that follows (stgcn_gcn3.hip's epilogue, on the SCALED accumulators:
+    // sums about a pivot per (wave, row), two rows per packed instruction; the scale leaves in the final merge)
+    if (p.stats) {
+      float *rs = rowstat + wave * 64 * ST;
+      const bool first = tile == (int)blockIdx.x;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float *e0 = rs + ST * (16 * m + 4 * g + 2 * qp), *e1 = e0 + ST;
+          f2 c;
+          c.x = first ? row16_sum(acc[0][m][2 * qp]) * 0.0625f : e0[2];
+          c.y = first ? row16_sum(acc[0][m][2 * qp + 1]) * 0.0625f : e1[2];
+          f2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < SLOTS; ++i)
+            if (sj[i] >= 0) {
+              const f2 v = f2{acc[i][m][2 * qp], acc[i][m][2 * qp + 1]} - c;
+              s1 += v;
+              s2 = __builtin_elementwise_fma(v, v, s2);
+            }
+          const float s1x = row16_sum(s1.x), s1y = row16_sum(s1.y);
+          const float s2x = row16_sum(s2.x), s2y = row16_sum(s2.y);
+          if (r == 0) {
+            e0[0] += s1x; e0[1] += s2x;
+            e1[0] += s1y; e1[1] += s2y;
+            if (first) { e0[2] = c.x; e1[2] = c.y; }
+          }
+        }
+    }
     PROF_T(3)
 #ifndef ABL_NO_EPI      // (timing ablation: no staged stores)
     // ---- epilogue: the tile leaves through LDS as whole rows (stgcn_gcn3.hip), scaled back by 2^-S -------------------
@@ -358,6 +399,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float
   const int tid = threadIdx.x;
   for (int e = tid; e < 64 * V; e += NW * 64) bias_l[e] = bias_cv ? bias_cv[e] : 0.f;
   for (int e = tid; e < (H3_LTOT + 1) * V; e += NW * 64) coef_l[e] = coef[e];
+  float *rowstat = coef_l + (H3_LTOT + 1) * V;
+  for (int e = tid; e < NW * 64 * ST; e += NW * 64) rowstat[e] = 0.f;
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
     case 0: wave_main<0>(p, lds, x, Wp, z); break;
@@ -369,6 +412,35 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float
     case 6: wave_main<6>(p, lds, x, Wp, z); break;
     default: wave_main<7>(p, lds, x, Wp, z); break;
   }
+  if (p.stats) {                  // [64][3] = (count, mean, M2) of the workgroup's tiles: the eight waves' entries merged
+    __syncthreads();
+    if (tid < 64) {
+      const int ntiles = (p.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+      const float per_joint = (float)(ntiles * F);
+      float nw[NW], mw[NW], qw[NW];
+      float msum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float *e = rowstat + (w * 64 + tid) * ST;
+        int nj = 0;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) nj += slot_joints[w][i] >= 0;
+        nw[w] = per_joint * (float)nj;
+        const float s1 = e[0] * p.inv_scale, s2 = e[1] * p.inv_scale * p.inv_scale, c = e[2] * p.inv_scale;
+        const float d = s1 / nw[w];
+        mw[w] = c + d;
+        qw[w] = fmaxf(s2 - s1 * d, 0.f);
+        msum = fmaf(nw[w], mw[w] - mw[0], msum);
+      }
+      const float n = per_joint * (float)V;
+      const float mean = mw[0] + msum / n;
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m2 += qw[w] + nw[w] * (mw[w] - mean) * (mw[w] - mean);
+      float *o = p.stats + (size_t)blockIdx.x * 192 + 3 * tid;
+      o[0] = n; o[1] = mean; o[2] = m2;
+    }
+  }
 }
 }  // namespace
 
@@ -377,6 +449,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float
 // [ltot + 1][53]: the column-form coefficient table + one row of zeros; bias_cv (64,53) or NULL; scale = 2^S.
 // T % 16 == 0, x / z 16-byte aligned.
 static unsigned long long *g_prof = nullptr;
+static float *g_stats = nullptr;
+// the next launches also write (count, mean, M2) per workgroup and channel: [min(tiles, 256)][64][3] (NULL: off)
+extern "C" void proto_gcn3h_stats(void *buf) { g_stats = reinterpret_cast<float *>(buf); }
 extern "C" void proto_gcn3h_profile(void *buf) { g_prof = reinterpret_cast<unsigned long long *>(buf); }   // [256][8][4] u64, -DPROFILE
 
 extern "C" int proto_gcn3h_forward(int N, int T, int ltot1, const float *x, const void *Wp, const float *coef,
@@ -384,9 +459,9 @@ extern "C" int proto_gcn3h_forward(int N, int T, int ltot1, const float *x, cons
   if (N <= 0 || T <= 0 || T % F != 0 || ltot1 != H3_LTOT + 1) return 1;
   Params p;
   p.T = T; p.tiles_per_seq = T / F; p.total_tiles = N * p.tiles_per_seq;
-  p.scale = scale; p.inv_scale = 1.f / scale; p.prof = g_prof;
+  p.scale = scale; p.inv_scale = 1.f / scale; p.prof = g_prof; p.stats = g_stats;
   const int blocks = p.total_tiles < 256 ? p.total_tiles : 256;
-  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)ltot1 * V) * sizeof(float);
+  const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)ltot1 * V + NW * 64 * ST) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gcn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gcn3h_kernel, dim3(blocks), dim3(NW * 64), lds, (hipStream_t)stream, p, x,
