@@ -121,6 +121,16 @@ for N, T in SIZES:
         tq = timed(lambda: gcn_op._gcn2_forward(x, Wp, cc, stream, bias if FORM != "r" else None, tables, form=form))
         msg += f'; prototype {tp:.3f} ms, product (no statistics) {tq:.3f} ms  -> x{tq / tp:.2f}'
     print(msg, flush=True)
+    if FORM == "r":
+        # the addend of the data gradient (the gradient of the residual branch), added in the store epilogue
+        add = (torch.randn(N, 64, T, V, generator=g) * 1e-4).to(dev)
+        proto.proto_gcn3h_addend(ctypes.c_void_p(add.data_ptr()))
+        got_a = run_proto(x, Wp16, scale, coef1, bias); torch.cuda.synchronize()
+        proto.proto_gcn3h_addend(None)
+        prod_a = gcn_op._gcn2_forward(x, Wp, cc, stream, None, tables, addend=add, form=1)
+        prod_a = prod_a[0] if isinstance(prod_a, tuple) else prod_a
+        print(f'   with the addend: prototype - (plain prototype + addend) {(got_a - (got + add)).abs().max().item():.1e}, '
+              f'vs product {((got_a - prod_a).abs().max() / prod_a.abs().max()).item():.2e} of range', flush=True)
     if FORM != "r":
         # the statistics epilogue: per-workgroup (count, mean, M2) per channel, merged (Chan) and compared with the
         # moments of the stored tensor and with what the product's gcn3 epilogue reports

@@ -49,7 +49,7 @@ constexpr int PW = (PIECES + NW - 1) / NW;       // 7
 constexpr int slot_joints[NW][SLOTS] = H3_SLOT_JOINTS;
 constexpr int plane0[NW] = {H3_PLANE0_0, H3_PLANE0_1, H3_PLANE0_2, H3_PLANE0_3, H3_PLANE0_4, H3_PLANE0_5, H3_PLANE0_6, H3_PLANE0_7};
 
-struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; unsigned long long *prof; float *stats; };
+struct Params { int T, tiles_per_seq, total_tiles; float scale, inv_scale; unsigned long long *prof; float *stats; const float *addend; };
 
 __device__ __forceinline__ unsigned lds_addr(const float *p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
@@ -369,13 +369,20 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *zrow = reinterpret_cast<float4 *>(zg + (size_t)16 * m * row_stride);
+        // the data gradient's addend (the gradient of the block's residual branch), added on the way out
+        const float4 *arow = p.addend ? reinterpret_cast<const float4 *>(p.addend + (zg - z) + (size_t)16 * m * row_stride) : nullptr;
         const float4 *srow = reinterpret_cast<const float4 *>(stg);
 #pragma unroll
         for (int it = 0; it < (NV4 + NW * 64 - 1) / (NW * 64); ++it) {
           const int e = it * NW * 64 + tid;
           if (e < NV4) {
             const int row = e / (RS / 4), c4 = e - row * (RS / 4);
-            zrow[(size_t)row * (row_stride / 4) + c4] = srow[e];
+            float4 v = srow[e];
+            if (arow) {
+              const float4 a4 = arow[(size_t)row * (row_stride / 4) + c4];
+              v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+            }
+            zrow[(size_t)row * (row_stride / 4) + c4] = v;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -450,6 +457,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3h_kernel(Params p, const float
 // T % 16 == 0, x / z 16-byte aligned.
 static unsigned long long *g_prof = nullptr;
 static float *g_stats = nullptr;
+static const float *g_addend = nullptr;
+// the next launches add this tensor (same shape as z) to the result on the way out (NULL: off)
+extern "C" void proto_gcn3h_addend(const void *buf) { g_addend = reinterpret_cast<const float *>(buf); }
 // the next launches also write (count, mean, M2) per workgroup and channel: [min(tiles, 256)][64][3] (NULL: off)
 extern "C" void proto_gcn3h_stats(void *buf) { g_stats = reinterpret_cast<float *>(buf); }
 extern "C" void proto_gcn3h_profile(void *buf) { g_prof = reinterpret_cast<unsigned long long *>(buf); }   // [256][8][4] u64, -DPROFILE
@@ -459,7 +469,7 @@ extern "C" int proto_gcn3h_forward(int N, int T, int ltot1, const float *x, cons
   if (N <= 0 || T <= 0 || T % F != 0 || ltot1 != H3_LTOT + 1) return 1;
   Params p;
   p.T = T; p.tiles_per_seq = T / F; p.total_tiles = N * p.tiles_per_seq;
-  p.scale = scale; p.inv_scale = 1.f / scale; p.prof = g_prof; p.stats = g_stats;
+  p.scale = scale; p.inv_scale = 1.f / scale; p.prof = g_prof; p.stats = g_stats; p.addend = g_addend;
   const int blocks = p.total_tiles < 256 ? p.total_tiles : 256;
   const size_t lds = ((size_t)2 * BUF + 64 * V + (size_t)ltot1 * V + NW * 64 * ST) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gcn3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
