@@ -19,7 +19,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
 
-constexpr int V = 53, C = 64, RING = 4;
+#ifndef RING_FRAMES
+#define RING_FRAMES 4
+#endif
+constexpr int V = 53, C = 64, RING = RING_FRAMES;     // 3: 48 KB, three workgroups per CU, but a second barrier per frame
 
 struct Split { h8 p, q; };
 __device__ __forceinline__ Split split8(const float (&v)[8]) {
@@ -40,7 +43,7 @@ __device__ __forceinline__ void load8(const float *p, float (&v)[8]) {
 }
 
 template <int FC>
-__global__ __launch_bounds__(256, 2) void tconv_f16w_kernel(int T, const float *__restrict__ x, const float *__restrict__ scale,
+__global__ __launch_bounds__(256, RING == 3 ? 3 : 2) void tconv_f16w_kernel(int T, const float *__restrict__ x, const float *__restrict__ scale,
                                                             const float *__restrict__ shift, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float wscale, float *__restrict__ out) {
   // ring[frame & 3][part][ks][kg][column 0..63][8 channels]: halves
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void tconv_f16w_kernel(int T, const float *
   // slot of (group g, column c): [ks' = g / 4][kg' = g % 4][c][8]; group wave + 4 j: ks' = j, kg' = wave
   _Float16 *wslot = &ring[0][0][0][wv][lane][0];
   auto put = [&](int t, bool in, const float (&raw)[2][8]) {
-    _Float16 *d = wslot + (size_t)(t & (RING - 1)) * (2 * 2 * 4 * 64 * 8);
+    _Float16 *d = wslot + (size_t)((t + RING) % RING) * (2 * 2 * 4 * 64 * 8);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float v[8];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void tconv_f16w_kernel(int T, const float *
     for (int nt = 0; nt < 4; ++nt) { hi[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      const _Float16 *fr = &ring[(s + p - 1) & (RING - 1)][0][0][0][0][0];
+      const _Float16 *fr = &ring[(s + p - 1 + RING) % RING][0][0][0][0][0];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void tconv_f16w_kernel(int T, const float *
       }
   };
   for (int s = t0; s < t0 + FC; ++s) {
+    if (RING == 3) __syncthreads();   // frame s - 2's slot is frame s + 1's: everybody has to be done reading it
     put(s + 1, inA, rawA);
     inA = fetch(s + 2, rawA);
     frame(s);
