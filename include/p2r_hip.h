@@ -78,7 +78,11 @@ int p2r_group_points(int b, int c, int n, int npoints, int nsample,
 
 /* replaces group_points_grad_kernel_wrapper (src/group_points.cpp:8-10,
  * src/group_points_gpu.cu:43-75).  grad_out (b,c,npoints,nsample) ->
- * grad_points (b,c,n), overwritten. */
+ * grad_points (b,c,n), overwritten.  Index lists that fit the LDS with n * slots
+ * <= 2^22 are summed in ascending slot order (deterministic, bit-equal to the
+ * sequential loop); larger problems use an order-free form (LDS scatter or global
+ * atomics: the same sums up to the order of the additions).  Slots whose index is
+ * outside [0, n) contribute nothing in the ordered forms. */
 int p2r_group_points_grad(int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx,
                           float *grad_points, void *stream);

@@ -41,6 +41,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         _lib.p2r_oracle_nms3d.restype = ctypes.c_int
+        _lib.p2r_oracle_nms2d.restype = ctypes.c_int
         _lib.p2r_oracle_opt_n_threads.restype = ctypes.c_int
     return _lib
 
@@ -182,4 +183,15 @@ def nms_3d(boxes, overlap_threshold, old_type=False, same_cls=False):
     n = lib().p2r_oracle_nms3d(K, stride, boxes.ctypes.data_as(ctypes.c_void_p),
                                ctypes.c_double(overlap_threshold), int(old_type), int(same_cls),
                                pick.ctypes.data_as(ctypes.c_void_p))
+    return [int(v) for v in pick[:n]]
+
+
+def nms_2d(boxes, overlap_threshold, old_type=False):
+    """Oracle of net_utils/nms.py:7-39.  boxes (K,5) float64 rows [x1,y1,x2,y2,score]."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+    K, stride = boxes.shape
+    assert stride == 5
+    pick = np.zeros(max(K, 1), dtype=np.int32)
+    n = lib().p2r_oracle_nms2d(K, boxes.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(overlap_threshold),
+                               int(old_type), pick.ctypes.data_as(ctypes.c_void_p))
     return [int(v) for v in pick[:n]]

@@ -419,3 +419,49 @@ int p2r_oracle_nms3d(int K, int stride, const double *boxes,
   free(ord); free(area); free(I);
   return npick;
 }
+
+/*
+ * /root/reference/net_utils/nms.py:7-39 nms_2d_faster, fp64, restated in TWO dimensions (on purpose not through
+ * p2r_oracle_nms3d: the product maps the 2-D boxes onto the 3-D kernel with a unit extent, and this is what that
+ * mapping is checked against).  boxes (K,5) rows = [x1,y1,x2,y2,score].
+ */
+int p2r_oracle_nms2d(int K, const double *boxes, double overlap_threshold, int old_type, int *pick) {
+  if (K <= 0) return 0;
+  nms_ent *ord = (nms_ent *)malloc(sizeof(nms_ent) * (size_t)K);
+  double *area = (double *)malloc(sizeof(double) * (size_t)K);
+  int *I = (int *)malloc(sizeof(int) * (size_t)K);
+  for (int k = 0; k < K; ++k) {
+    const double *r = boxes + (size_t)k * 5;
+    ord[k].s = r[4];
+    ord[k].i = k;
+    area[k] = (r[2] - r[0]) * (r[3] - r[1]); /* :13 */
+  }
+  qsort(ord, (size_t)K, sizeof(nms_ent), nms_cmp);
+  for (int k = 0; k < K; ++k) I[k] = ord[k].i;
+  int size = K, npick = 0;
+  while (size != 0) { /* :17 */
+    const int last = size;
+    const int i = I[last - 1];
+    pick[npick++] = i;
+    const double *bi = boxes + (size_t)i * 5;
+    int w = 0;
+    for (int t = 0; t < last - 1; ++t) {
+      const int r = I[t];
+      const double *br = boxes + (size_t)r * 5;
+      const double xx1 = fmax(bi[0], br[0]), yy1 = fmax(bi[1], br[1]);
+      const double xx2 = fmin(bi[2], br[2]), yy2 = fmin(bi[3], br[3]);
+      const double ww = fmax(0.0, xx2 - xx1), h = fmax(0.0, yy2 - yy1);
+      double o;
+      if (old_type) {
+        o = (ww * h) / area[r]; /* :31 */
+      } else {
+        const double inter = ww * h;
+        o = inter / (area[i] + area[r] - inter); /* :33-34 */
+      }
+      if (!(o > overlap_threshold)) I[w++] = r; /* :36 */
+    }
+    size = w;
+  }
+  free(ord); free(area); free(I);
+  return npick;
+}

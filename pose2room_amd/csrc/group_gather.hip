@@ -164,7 +164,10 @@ __global__ __launch_bounds__(GG_THREADS) void group_grad_sort_kernel(
   float *gp = grad_points + ((size_t)batch * c + l0) * n;
   const int tid = threadIdx.x;
 
-  for (int t = tid; t < NP; t += GG_THREADS) keys[t] = t < S ? ((unsigned)id[t] << SB) | (unsigned)t : 0xffffffffu;
+  // an index outside [0, n) takes the padding key: it sorts behind every destination and is never summed (the scan form
+  // ignores such entries too; shifting it would drop its high bits and could alias a valid destination)
+  for (int t = tid; t < NP; t += GG_THREADS)
+    keys[t] = (t < S && (unsigned)id[t] < (unsigned)n) ? ((unsigned)id[t] << SB) | (unsigned)t : 0xffffffffu;
   // the gradient rows are fetched while the network runs (plain loads into registers would not survive the barriers'
   // register pressure for GC = 16: staged first, the loads of the last rows overlap the first sort stages)
   for (int l = 0; l < GC; ++l)
@@ -285,9 +288,14 @@ int group_backward(int b, int c, int n, int S, const float *grad_out, const int 
       if (gfit >= 8 && c > 4) return group_grad_sort_launch<8>(b, c, n, S, sp, NP, SB, grad_out, idx, grad_points, st);
       if (gfit >= 4) return group_grad_sort_launch<4>(b, c, n, S, sp, NP, SB, grad_out, idx, grad_points, st);
     }
-    if (fit >= 17 && c > 8) return group_grad_scan_launch<16>(b, c, n, S, sp, grad_out, idx, grad_points, st);
-    if (fit >= 9 && c > 4) return group_grad_scan_launch<8>(b, c, n, S, sp, grad_out, idx, grad_points, st);
-    return group_grad_scan_launch<4>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+    // scan form: every destination walks the whole index list -- O(n * S / 4) LDS reads per workgroup.  Bounded: past
+    // 2^22 (destination, slot) pairs (the P2RNet shapes are n <= 1024, S <= 2048) the order-free forms below take over
+    // (LDS scatter / global atomics: same sums up to the order of the additions, documented in include/p2r_hip.h)
+    if ((long long)n * sp <= (1LL << 22)) {
+      if (fit >= 17 && c > 8) return group_grad_scan_launch<16>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+      if (fit >= 9 && c > 4) return group_grad_scan_launch<8>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+      return group_grad_scan_launch<4>(b, c, n, S, sp, grad_out, idx, grad_points, st);
+    }
   }
   const size_t row_bytes = (size_t)n * sizeof(float);
   // Channel chunk: as many rows as fit 64 KiB of LDS (2 blocks / CU), up to 16,

@@ -204,6 +204,11 @@ __device__ __forceinline__ void t3_wave_main(const T3Params &p, float *lds, cons
   // padding value.  Either way a wave issues N16 vector-memory operations per slice (t3_wait_vm<N16>): the 32 pieces
   // of a row boundary never fill a whole 64-lane instruction.
   constexpr int N16 = (PIECES16 - WAVE + NW - 1) / NW;
+  // t3_wait_vm<N16> counts one vector-memory operation per piece instruction: at a sequence edge the lanes outside take
+  // the LDS fill instead, and the count only holds while every 64-lane piece instruction keeps at least one DMA lane
+  // (the compiler's execz skip would otherwise drop the instruction and the wait would return early)
+  static_assert(TAPS == 1 || ((T3_RSP3 - T3_RS) / 4 < 64 && T3_OFF3 / 4 < 64 && (T3_RSP3 - T3_OFF3 - T3_RS) / 4 < 64),
+                "an all-outside run of 16-byte pieces must be shorter than one 64-lane piece instruction");
   auto copy_slice = [&](float *buf, const float *base, bool lo, bool hi) {
     if (TAPS == 1 || (lo && hi)) {
 #pragma unroll

@@ -168,9 +168,9 @@ def parse_predictions(est_data, gt_data, config_dict, return_device=False):
     maxs = corners.max(dim=2).values
     score = obj_prob_t.to(torch.float64).unsqueeze(-1)
     if not config_dict['use_3d_nms']:
-        # 2D (x,z) NMS == 3D NMS on boxes with a unit y extent
-        zeros, ones = torch.zeros_like(mins[..., :1]), torch.ones_like(mins[..., :1])
-        boxes = torch.cat([mins[..., 0:1], zeros, mins[..., 2:3], maxs[..., 0:1], ones, maxs[..., 2:3], score], -1)
+        # 2D (x,z) NMS (nms_2d_faster, ap_helper.py:198-214) == 3D NMS on boxes with a unit y extent, bit for bit
+        # (nms.boxes_2d_as_3d; pinned by G2's 2-D pick lists and the `use_3d_nms: False` fixture of G7)
+        boxes = nms_hip.boxes_2d_as_3d(torch.cat([mins[..., 0:1], mins[..., 2:3], maxs[..., 0:1], maxs[..., 2:3], score], -1))
         same_cls = False
     elif not config_dict['cls_nms']:
         boxes = torch.cat([mins, maxs, score], -1)

@@ -1,6 +1,7 @@
-"""3D NMS on the HIP kernel.
+"""2D / 3D NMS on the HIP kernel.
 
-Mirror of the reference's net_utils/nms.py: `nms_3d_faster(boxes (K,7),
+Mirror of the reference's net_utils/nms.py: `nms_2d_faster(boxes (K,5),
+overlap_threshold, old_type=False) -> list[int]` (:7-39), `nms_3d_faster(boxes (K,7),
 overlap_threshold, old_type=False) -> list[int]` (:41-77) and
 `nms_3d_faster_samecls(boxes (K,8), ...)` (:79-119) keep their signatures and
 return the picked indices in pick order.  They accept a NumPy array (copied to
@@ -69,3 +70,25 @@ def nms_3d_faster(boxes, overlap_threshold, old_type=False):
 def nms_3d_faster_samecls(boxes, overlap_threshold, old_type=False):
     """boxes (K,8) rows [...,score,cls]: only same-class boxes suppress each other."""
     return _pick_list(boxes, overlap_threshold, old_type, True)
+
+
+def boxes_2d_as_3d(boxes):
+    """(..., 5) rows [x1,y1,x2,y2,score] -> (..., 7) rows [x1,0,y1,x2,1,y2,score]: a unit extent along the middle axis.
+    The 3-D kernel's arithmetic on these rows IS the 2-D arithmetic of nms.py:7-39, bit for bit: the volume
+    (x2-x1)*(1-0)*(y2-y1) and the intersection l*max(0,1-0)*h multiply by exactly 1.0 in between, which changes no
+    bit of an IEEE product."""
+    if isinstance(boxes, np.ndarray):
+        b = np.ascontiguousarray(boxes, dtype=np.float64)
+        zeros, ones = np.zeros_like(b[..., :1]), np.ones_like(b[..., :1])
+        return np.concatenate([b[..., 0:1], zeros, b[..., 1:2], b[..., 2:3], ones, b[..., 3:4], b[..., 4:5]], -1)
+    b = boxes.to(dtype=torch.float64)
+    zeros, ones = torch.zeros_like(b[..., :1]), torch.ones_like(b[..., :1])
+    return torch.cat([b[..., 0:1], zeros, b[..., 1:2], b[..., 2:3], ones, b[..., 3:4], b[..., 4:5]], -1)
+
+
+def nms_2d_faster(boxes, overlap_threshold, old_type=False):
+    """boxes (K,5) rows [x1,y1,x2,y2,score] -> picked indices, best score first (nms.py:7-39; the `use_3d_nms: False`
+    branch of ap_helper.py:198-214 calls it with the (x, z) extents of the predicted boxes)."""
+    if boxes.shape[-1] != 5:
+        raise ValueError("nms_2d_faster: boxes must be (K,5) [x1,y1,x2,y2,score]")
+    return _pick_list(boxes_2d_as_3d(boxes), overlap_threshold, old_type, False)

@@ -70,6 +70,12 @@ def random_boxes(K, seed, stride=8, ncls=3):
     return np.ascontiguousarray(b[:, :stride])
 
 
+def boxes_xz(boxes):
+    """(K,>=7) rows [x1,y1,z1,x2,y2,z2,score,...] -> (K,5) rows [x1,z1,x2,z2,score]: the 2-D boxes the reference's
+    `use_3d_nms: False` branch builds (ap_helper.py:201-207)."""
+    return np.ascontiguousarray(boxes[:, [0, 2, 3, 5, 6]])
+
+
 def _hash_uniform(n, k):
     """n deterministic pseudo-random numbers in [-1, 1) from integer arithmetic only
     (exact on every platform / torch version): a multiply-xorshift hash of (index, key)."""

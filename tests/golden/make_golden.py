@@ -10,7 +10,7 @@ tests/cases.py) and the reference's outputs.
   G1  nn_distance: the reference's own demo inputs (net_utils/nn_distance.py:63-94,
       np.random.seed(0)) and the three loss call shapes, all modes, with the
       autograd gradients of a fixed scalarisation.
-  G2  nms_3d_faster / nms_3d_faster_samecls pick lists on seeded boxes.
+  G2  nms_2d_faster / nms_3d_faster / nms_3d_faster_samecls pick lists on seeded boxes.
   G6  the nine _ext ops: outputs of the CPU restatement (oracle/p2r_oracle.c) on
       seeded random and adversarial clouds.  The reference has no CPU path and
       no tests for these, so G6 pins the *restatement* against regressions; it
@@ -80,7 +80,7 @@ def g1():
 
 def g2():
     _ref_path()
-    from net_utils.nms import nms_3d_faster, nms_3d_faster_samecls
+    from net_utils.nms import nms_2d_faster, nms_3d_faster, nms_3d_faster_samecls
     out = {}
     for K in (1, 2, 16, 128, 300):
         boxes = cases.random_boxes(K, seed=K)
@@ -90,6 +90,9 @@ def g2():
                 tag = f"{K}_{int(thr * 100)}_{int(old)}"
                 out[f"pick_{tag}"] = np.asarray(nms_3d_faster(boxes[:, :7], thr, old), dtype=np.int32)
                 out[f"pickcls_{tag}"] = np.asarray(nms_3d_faster_samecls(boxes, thr, old), dtype=np.int32)
+                # nms_2d_faster (nms.py:7-39) on the (x, z) extents + score of the same boxes -- what
+                # ap_helper.py:198-214 builds when use_3d_nms is false
+                out[f"pick2d_{tag}"] = np.asarray(nms_2d_faster(cases.boxes_xz(boxes), thr, old), dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "g2_nms.npz"), **out)
     print("g2", len(out), "arrays")
 

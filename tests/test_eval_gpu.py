@@ -50,6 +50,30 @@ def test_parse_predictions_from_reference_endpoints(dev, tag, B, T):
                                    rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag,B,T", [('g3u', 1, 768), ('g3f', 2, 512)])
+def test_parse_predictions_2d_nms_branch(dev, tag, B, T):
+    """`use_3d_nms: False` (ap_helper.py:198-214 -> nms_2d_faster on the (x, z) extents): keep masks equal to the
+    reference's on the reference's own end points, at the configured threshold and at selective ones, both overlap
+    definitions (G5b, tests/golden/make_nms2d_golden.py)."""
+    from pose2room_amd.net_utils import ap_helper
+    from pose2room_amd.p2rnet import P2RConfig, default_config
+    from pose2room_amd.p2rnet.synthetic import make_batch
+    z = np.load(G)
+    z2 = np.load(os.path.join(os.path.dirname(G), 'g5b_nms2d.npz'))
+    data = make_batch(B, T, seed=100 + T, device=dev)
+    ep = _endpoints_from_golden(z, tag, dev)
+    for iou in (0.25, 0.7, 0.9, 0.97):
+        for old in (False, True):
+            cfg = P2RConfig(default_config('test', data={'num_frames': T},
+                                           test={'remove_far_box': False, 'use_3d_nms': False, 'use_old_type_nms': old,
+                                                 'nms_iou': iou}), device=dev)
+            assert cfg.eval_config['use_3d_nms'] is False
+            eval_dict, _ = ap_helper.parse_predictions(ep, data, cfg.eval_config)
+            want = z2[f'{tag}_pred_mask_2d_{int(round(iou * 100))}_{int(old)}']
+            assert eval_dict['pred_mask'].dtype == np.uint8
+            assert np.array_equal(eval_dict['pred_mask'], want), (tag, iou, old, int(eval_dict['pred_mask'].sum()), int(want.sum()))
+
+
 # ---- decision-level comparison of end-to-end keep masks -------------------------------------------------------------
 # `north_star`: keep masks bit-exact.  From the reference's end points they are (test above).  End to end the inputs of
 # the parse are OUR network's fp32 outputs, equal to the reference's to ~1e-5, and the mask is a function of DECISIONS

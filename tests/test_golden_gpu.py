@@ -41,6 +41,7 @@ def test_g2_nms(dev):
                 tag = f"{K}_{int(thr * 100)}_{int(old)}"
                 assert nms.nms_3d_faster(boxes[:, :7], thr, old) == z[f"pick_{tag}"].tolist()
                 assert nms.nms_3d_faster_samecls(boxes, thr, old) == z[f"pickcls_{tag}"].tolist()
+                assert nms.nms_2d_faster(cases.boxes_xz(boxes), thr, old) == z[f"pick2d_{tag}"].tolist()
 
 
 def test_g6_ext_ops(dev):

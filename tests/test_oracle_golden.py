@@ -53,6 +53,7 @@ def test_g2_nms_matches_reference(oracle):
                 tag = f"{K}_{int(thr * 100)}_{int(old)}"
                 assert oracle.nms_3d(boxes[:, :7], thr, old) == z[f"pick_{tag}"].tolist()
                 assert oracle.nms_3d(boxes, thr, old, True) == z[f"pickcls_{tag}"].tolist()
+                assert oracle.nms_2d(cases.boxes_xz(boxes), thr, old) == z[f"pick2d_{tag}"].tolist()
 
 
 def test_g6_ext_ops_stable(oracle):
