@@ -34,7 +34,7 @@ extern "C" {
 #define P2R_EINVAL (-22)
 
 /* Library / build identification (sanity check for loaders). */
-int p2r_abi_version(void);          /* currently 2; 1 = rounds 1-2 (p2r_bn_finalize without `width`, two-entry statistics partials) */
+int p2r_abi_version(void);          /* currently 3 (adds the split16 entry points); 2 = rounds 3-5; 1 = rounds 1-2 (p2r_bn_finalize without `width`) */
 const char *p2r_build_arch(void);   /* "gfx950" */
 
 /* ---- pointnet2_ops._ext: the nine reference launchers ------------------ */
@@ -632,6 +632,44 @@ int p2r_vote_finish_grad(int b, int s, int C, const float *d_xyz, const float *d
  * expression of `torch.argmin(torch.abs(cum.unsqueeze(-1) - target.unsqueeze(1)), dim=1)` without its (b,t,s) tensor).
  * cum (b,t), target (b,s) f32; inds (b,s) int64; t <= 40000. */
 int p2r_nearest_prefix(int b, int t, int s, const float *cum, const float *target, long long *inds, void *stream);
+
+/* ---- opt-in `split16` arithmetic of the ST-GCN blocks (csrc/split16.h) -----------------------------------------------
+ * Same operators as the exact-fp32 entry points above (reference models/p2rnet/modules/stgcn_layers.py:50-67,399-439 and
+ * their autograd), every fp32 product formed as three v_mfma_f32_16x16x32_f16 products of two-part fp16 operands with
+ * fp32 accumulation.  Operand tensors are lifted into fp16's range by a power of two derived ON THE DEVICE from a range
+ * word: `*_amax` arguments point at one uint32 = the float bits of max |x| over the tensor (NULL: scale 1).  Weights
+ * arrive pre-split (fp16 planes in the kernel's lane order) with the inverse of their power-of-two scale as a device
+ * float.  The default (exact) mode never calls these. */
+
+/* range word of a tensor: *amax_bits = float bits of max |x[i]|, i < n (one read of x). */
+int p2r_absmax_bits(long long n, const float *x, unsigned *amax_bits, void *stream);
+
+/* p2r_bn_bwd_apply in the chain's form (ReLU mask BYTES, `relu` = 3) that also leaves the range word of dx. */
+int p2r_bn_bwd_apply_amax(int N, int C, int L, const float *dy, const unsigned char *mask, const float *x,
+                          const float *mean, const float *invstd, const float *kscale, const float *m1,
+                          const float *m2, float *dx, float *dres, unsigned *amax_bits, void *stream);
+/* p2r_bn_apply with ReLU (res / mask optional) that also leaves the range word of y. */
+int p2r_bn_apply_amax(int N, int C, int L, const float *x, const float *scale, const float *shift, const float *res,
+                      float *y, unsigned char *mask, unsigned *amax_bits, void *stream);
+/* p2r_stgcn_tconv_weight_grad_dz that also leaves the range word of dz. */
+int p2r_stgcn_tconv_weight_grad_dz_amax(int N, int T, int V, int taps, const float *x, const float *fin,
+                                        const float *dout, const float *dh, const float *m12, float *dz, int n_blocks,
+                                        float *dw_partial, float *dbias_partial, unsigned *amax_bits, void *stream);
+
+/* The (3,1) temporal convolution of p2r_stgcn_tconv3_forward (taps = 3, V = 53, T % 16 == 0) in split16 arithmetic
+ * (csrc/stgcn_tconvh.hip).  x, scale, shift, bias, out, bwd_z, bwd_fin as there.
+ *   Wh    fp16 [2 parts][3 taps][2][4][64 lanes][8]: the parts of 2^S_w W[tap][co][ci] in A-operand order,
+ *         Wh[part][tap][ks][w][16 kg + r][i] = part of 2^S_w W[tap][16 w + r][32 ks + 8 kg + i]   (16-byte aligned)
+ *   winv  device float: 2^-S_w
+ *   x_amax range word of x (the data gradient's incoming gradient) or NULL (forward: the activation relu(x*scale+shift)
+ *         is used at scale 1, clamped to fp16's largest finite value)
+ *   stats_partial [*n_partials][64][3] = (count, mean, M2) per workgroup and channel (forward) or [*n_partials][64][2]
+ *         (bwd_z / bwd_fin given: the two sums of the BatchNorm + ReLU backward); *n_partials = N * T / chunk with
+ *         chunk = the longest of 64 / 32 / 16 frames dividing T; out == NULL queries it. */
+int p2r_stgcn_tconvh_forward(int N, int T, int V, const float *x, const float *scale, const float *shift,
+                             const void *Wh, const float *winv, const float *bias, float *out, float *stats_partial,
+                             int *n_partials, const float *bwd_z, const float *bwd_fin, const unsigned *x_amax,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P2R_LIB_PATH") or os.path.join(_HERE, "libp2r_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "p2r_hip.h")
 
-ABI_VERSION = 2     # p2r_abi_version() of the library this loader was written against (include/p2r_hip.h)
+ABI_VERSION = 3     # p2r_abi_version() of the library this loader was written against (include/p2r_hip.h)
 
 _lib = None
 

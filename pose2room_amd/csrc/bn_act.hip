@@ -77,14 +77,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int L, const float
 }
 
 // y = relu?(x * scale[c] + shift[c] + res)
-template <bool RELU, bool RES>
+// AMAX (split16 mode): the float bits of max |y| over the tensor are merged into *amax (zeroed by the caller) -- the
+// range word of the split16 graph conv that consumes y (split16.h)
+__device__ __forceinline__ void bn_block_amax(unsigned m, unsigned *amax) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(amax, m);
+}
+__device__ __forceinline__ unsigned bn_abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+template <bool RELU, bool RES, bool AMAX = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int chunks,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift,
                                                               const float *__restrict__ res,
                                                               float *__restrict__ y,
-                                                              unsigned char *__restrict__ mask) {
+                                                              unsigned char *__restrict__ mask,
+                                                              unsigned *__restrict__ amax = nullptr) {
+  unsigned am = 0;
   // last rows first: the producer (temporal conv, ascending tiles) wrote them last and part of them is still on
   // chip (-3 % in the step); the consumer that follows starts with the rows this pass writes last
   const int bid = (int)(gridDim.x - 1 - blockIdx.x);
@@ -108,6 +119,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       }
       if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       st_stream(y + base + i, v);
+      if (AMAX) am = max(max(am, bn_abs_bits(v.x)), max(max(bn_abs_bits(v.y), bn_abs_bits(v.z)), bn_abs_bits(v.w)));
       if (RELU && mask)     // one byte per element (y > 0): the backward reads 1 B instead of the 4 B of y
         *reinterpret_cast<uchar4 *>(mask + base + i) = make_uchar4(v.x > 0.f, v.y > 0.f, v.z > 0.f, v.w > 0.f);
     }
@@ -118,6 +130,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       if (RES) v += res[base + j];
       if (RELU) v = fmaxf(v, 0.f);
       y[base + j] = v;
+      if (AMAX) am = max(am, bn_abs_bits(v));
       if (RELU && mask) mask[base + j] = v > 0.f;
     }
   } else {
@@ -126,9 +139,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int C, int L, int 
       if (RES) v += res[base + j];
       if (RELU) v = fmaxf(v, 0.f);
       y[base + j] = v;
+      if (AMAX) am = max(am, bn_abs_bits(v));
       if (RELU && mask) mask[base + j] = v > 0.f;
     }
   }
+  if (AMAX) bn_block_amax(am, amax);
 }
 
 // partial[row] = (sum g, sum g * xhat),  g = dy * (RELU ? y > 0 : 1),  xhat = (x - mean) * invstd
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int C, int L,
 }
 
 // dx = k[c] * (g - m1[c] - xhat * m2[c]);  dres = g
-template <int MASK, bool RES>
+template <int MASK, bool RES, bool AMAX = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, int chunks,
                                                                   const float *__restrict__ dy,
                                                                   const float *__restrict__ y,
@@ -198,8 +213,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
                                                                   const float *__restrict__ mscale,
                                                                   const float *__restrict__ mshift,
                                                                   float *__restrict__ dx,
-                                                                  float *__restrict__ dres) {
+                                                                  float *__restrict__ dres,
+                                                                  unsigned *__restrict__ amax = nullptr) {
   constexpr bool RELU = MASK == 1;
+  unsigned am = 0;                      // AMAX: max |dx| (split16.h), merged into *amax (zeroed by the caller)
   const int rowi = blockIdx.x / chunks;
   const int chunk = blockIdx.x % chunks;
   const int c = rowi % C;
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
       one(g4.x, y4.x, x4.x, o.x, rr.x); one(g4.y, y4.y, x4.y, o.y, rr.y);
       one(g4.z, y4.z, x4.z, o.z, rr.z); one(g4.w, y4.w, x4.w, o.w, rr.w);
       st_stream(dx + base + j, o);
+      if (AMAX) am = max(max(am, bn_abs_bits(o.x)), max(max(bn_abs_bits(o.y), bn_abs_bits(o.z)), bn_abs_bits(o.w)));
       if (RES) st_stream(dres + base + j, rr);
     }
   }
@@ -242,8 +260,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int C, int L, 
     float o, rr;
     one(dy[base + j], RELU ? y[base + j] : (MASK == 3 ? (float)m8[base + j] : 0.f), x[base + j], o, rr);
     dx[base + j] = o;
+    if (AMAX) am = max(am, bn_abs_bits(o));
     if (RES) dres[base + j] = rr;
   }
+  if (AMAX) bn_block_amax(am, amax);
 }
 
 }  // namespace
@@ -311,6 +331,44 @@ extern "C" int p2r_bn_bwd_apply(int N, int C, int L, const float *dy, const floa
   else if (dres) P2R_BWA(0, true);
   else P2R_BWA(0, false);
 #undef P2R_BWA
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// split16 mode: p2r_bn_bwd_apply for the chain's form (mask bytes, relu = 3) that also leaves the float bits of max |dx|
+// in *amax_bits (split16.h: the range word of the split16 temporal conv's data gradient, which consumes dx).
+extern "C" int p2r_bn_bwd_apply_amax(int N, int C, int L, const float *dy, const unsigned char *mask, const float *x,
+                                     const float *mean, const float *invstd, const float *kscale, const float *m1,
+                                     const float *m2, float *dx, float *dres, unsigned *amax_bits, void *stream) {
+  if (N < 0 || C <= 0 || L <= 0 || !amax_bits) return P2R_EINVAL;
+  hipStream_t st = p2r_stream(stream);
+  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0) return P2R_OK;
+  const int rows = N * C, chunks = bn_chunks(rows, L);
+  dim3 grid(rows * chunks), blk(BN_THREADS);
+  const float *y = reinterpret_cast<const float *>(mask), *none = nullptr;
+  if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<3, true, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd,
+                               kscale, m1, m2, none, none, dx, dres, amax_bits);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<3, false, true>), grid, blk, 0, st, C, L, chunks, dy, y, x, mean, invstd,
+                          kscale, m1, m2, none, none, dx, dres, amax_bits);
+  P2R_LAUNCH_CHECK();
+  return P2R_OK;
+}
+
+// split16 mode: p2r_bn_apply with ReLU (+ residual, + mask bytes) that also leaves the float bits of max |y| in *amax_bits
+// (the range word of the split16 graph conv that consumes y).
+extern "C" int p2r_bn_apply_amax(int N, int C, int L, const float *x, const float *scale, const float *shift,
+                                 const float *res, float *y, unsigned char *mask, unsigned *amax_bits, void *stream) {
+  if (N < 0 || C <= 0 || L <= 0 || !amax_bits) return P2R_EINVAL;
+  hipStream_t st = p2r_stream(stream);
+  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0) return P2R_OK;
+  const int rows = N * C, chunks = bn_chunks(rows, L);
+  dim3 grid(rows * chunks), blk(BN_THREADS);
+  if (res) hipLaunchKernelGGL((bn_apply_kernel<true, true, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, mask, amax_bits);
+  else hipLaunchKernelGGL((bn_apply_kernel<true, false, true>), grid, blk, 0, st, C, L, chunks, x, scale, shift, res, y, mask, amax_bits);
   P2R_LAUNCH_CHECK();
   return P2R_OK;
 }

@@ -211,12 +211,17 @@ __host__ __device__ constexpr int tw_row(int cols) {   // + room for the last (p
 //   dz = scale * ((z * scale + shift > 0 ? dh : 0) - m1 - (z - mean) * invstd * m2)       (bn_bwd_apply, mask form 2)
 // leaves from the staging pass and the separate apply pass (read dh, read z, write dz) is gone: one more read and
 // one write of the tensor in a kernel that leaves two thirds of the HBM rate unused.
-template <int TAPS, int VS, int F = TW_F, bool DZ = false, bool XF = true>
+// AMAX (DZ only; split16 mode): the float bits of max |dz| are merged into *amax (zeroed by the launcher) -- the range word
+// of the split16 graph-conv gradient kernels that consume dz (split16.h).
+template <int TAPS, int VS, int F = TW_F, bool DZ = false, bool XF = true, bool AMAX = false>
 __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_kernel(
     int n_seq, int T, int V_, int row_d_, int row_h_, const float *__restrict__ x,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ dout,
     float *__restrict__ dw_partial, float *__restrict__ dbias_partial, const float *__restrict__ dh = nullptr,
-    const float *__restrict__ fin = nullptr, const float *__restrict__ m12 = nullptr, float *__restrict__ dz = nullptr) {
+    const float *__restrict__ fin = nullptr, const float *__restrict__ m12 = nullptr, float *__restrict__ dz = nullptr,
+    unsigned *__restrict__ amax = nullptr) {
+  static_assert(!AMAX || DZ, "the range word belongs to dz");
+  unsigned am = 0;
   constexpr int HALO = (TAPS - 1) / 2;
   // 64-column chunks of the h tile per row (the unrolled instances stage only the chunks that hold columns: the pad
   // columns behind them are zeroed once, below, and never written again)
@@ -336,8 +341,12 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
           const float o = kk * (gq - a1 - xh * a2);
           // columns of the halo frame in front (chunk ZI0 only) are another tile's; past the tile's last frame the
           // descriptor drops the store
-          if (64 * i >= HALO * VS || lane + 64 * i >= HALO * VS)
+          if (64 * i >= HALO * VS || lane + 64 * i >= HALO * VS) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rsrc, lane4 + 4 * (ld_col0 + 64 * i), 0, 0);
+            // (the same range test the descriptor applies to the store: what it drops is not part of dz)
+            if (AMAX && (unsigned)(lane4 + 4 * (ld_col0 + 64 * i)) < (unsigned)ld_zbytes)
+              am = max(am, __float_as_uint(o) & 0x7fffffffu);
+          }
         }
       }
 #pragma unroll
@@ -417,6 +426,11 @@ __global__ __launch_bounds__(TW_THREADS, TW_WAVES == 8 ? 2 : 1) void tconv_dw_ke
       }
     }
   }
+  if constexpr (AMAX) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off, 64));
+    if (lane == 0 && am != 0) atomicMax(amax, am);
+  }
   if (dbias_partial) {
 #pragma unroll
     for (int hh = 0; hh < TC_C / (TW_THREADS / 64); ++hh) {
@@ -482,11 +496,11 @@ extern "C" int p2r_stgcn_tconv_forward(int N, int T, int V, int taps, const floa
                    : tconv_forward_launch<1>(N, T, V, x, scale, shift, W, bias, out, stats_partial, n_partials, stream);
 }
 
-template <int TAPS, int VS, int F = TW_F, bool DZ = false>
+template <int TAPS, int VS, int F = TW_F, bool DZ = false, bool AMAX = false>
 static int tconv_dw_launch(int N, int T, int V, const float *x, const float *scale, const float *shift,
                            const float *dout, int n_blocks, float *dw_partial, float *dbias_partial,
                            void *stream, const float *dh = nullptr, const float *fin = nullptr, const float *m12 = nullptr,
-                           float *dz = nullptr) {
+                           float *dz = nullptr, unsigned *amax = nullptr) {
   constexpr int HALO = (TAPS - 1) / 2;
   const int row_d = tw_row(F * V), row_h = tw_row((F + 2 * HALO) * V);
   const size_t lds = (size_t)TC_C * (row_d + row_h) * sizeof(float);
@@ -494,10 +508,11 @@ static int tconv_dw_launch(int N, int T, int V, const float *x, const float *sca
   if ((long long)T * V >= (1LL << 29)) return P2R_EINVAL;        // the kernel addresses a row with 32-bit byte offsets
   static unsigned char lds_ok[2][P2R_MAX_DEVICES];
   if (scale || DZ) {     // with the input transform relu(x * scale + shift)
-    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, DZ, true>, lds_ok[0]);
+    hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, DZ, true, AMAX>, lds_ok[0]);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, DZ, true>), dim3(n_blocks), dim3(TW_THREADS), lds, p2r_stream(stream), N,
-                       T, V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin, m12, dz);
+    hipLaunchKernelGGL((tconv_dw_kernel<TAPS, VS, F, DZ, true, AMAX>), dim3(n_blocks), dim3(TW_THREADS), lds,
+                       p2r_stream(stream), N, T, V, row_d, row_h, x, scale, shift, dout, dw_partial, dbias_partial, dh, fin,
+                       m12, dz, amax);
   } else {
     hipError_t e = p2r_allow_big_lds(tconv_dw_kernel<TAPS, VS, F, false, false>, lds_ok[1]);
     if (e != hipSuccess) return (int)e;
@@ -541,4 +556,17 @@ extern "C" int p2r_stgcn_tconv_weight_grad_dz(int N, int T, int V, int taps, con
   if (N == 0) return P2R_OK;
   return tconv_dw_launch<3, 53, TW_F, true>(N, T, V, x, fin + 128, fin + 192, dout, n_blocks, dw_partial, dbias_partial,
                                             stream, dh, fin, m12, dz);
+}
+
+// split16 mode: the same launch, additionally leaving the float bits of max |dz| in *amax_bits (split16.h).
+extern "C" int p2r_stgcn_tconv_weight_grad_dz_amax(int N, int T, int V, int taps, const float *x, const float *fin,
+                                                   const float *dout, const float *dh, const float *m12, float *dz,
+                                                   int n_blocks, float *dw_partial, float *dbias_partial,
+                                                   unsigned *amax_bits, void *stream) {
+  if (N < 0 || T <= 0 || V != 53 || taps != 3 || n_blocks < 1 || !fin || !dh || !m12 || !dz || !amax_bits) return P2R_EINVAL;
+  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned), p2r_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  if (N == 0) return P2R_OK;
+  return tconv_dw_launch<3, 53, TW_F, true, true>(N, T, V, x, fin + 128, fin + 192, dout, n_blocks, dw_partial,
+                                                  dbias_partial, stream, dh, fin, m12, dz, amax_bits);
 }

@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from . import math_mode
 
 
 def _rows(x):
@@ -92,9 +93,17 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().p2r_bn_apply(N, C, L, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
-                                           int(relu), _lib.ptr(y), _lib.ptr(mask), _lib.current_stream(x.device)),
-                   "bn_apply")
+        if relu and want_mask and math_mode.split16() and x.dim() == 4 and N > 0:
+            # split16 mode: y is (typically) the next block's graph-conv input -- its range word leaves with it
+            word = math_mode.new_word(x.device)
+            _lib.check(_lib.lib().p2r_bn_apply_amax(N, C, L, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
+                                                    _lib.ptr(y), _lib.ptr(mask), _lib.ptr(word),
+                                                    _lib.current_stream(x.device)), "bn_apply_amax")
+            math_mode.announce(y, word)
+        else:
+            _lib.check(_lib.lib().p2r_bn_apply(N, C, L, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res),
+                                               int(relu), _lib.ptr(y), _lib.ptr(mask), _lib.current_stream(x.device)),
+                       "bn_apply")
     return (y, mask) if want_mask else y
 
 
@@ -179,6 +188,7 @@ class _FusedBNAct(Function):
         y, mask = _apply(x, fin[2], fin[3], res_c, relu, want_mask=True)
         ctx.save_for_backward(x, mask, fin)
         ctx.relu = relu
+        ctx.split = math_mode.split16() and relu and x.dim() == 4
         ctx.has_res = res is not None
         ctx.lazy_res = lazy_res if (isinstance(lazy_res, ResLink) and relu and res is not None) else None
         ctx.link = link if relu else None
@@ -223,15 +233,24 @@ class _FusedBNAct(Function):
             tot_ = bwd_finalize(part_, N * L)                 # (dbeta, dgamma, m1, m2)
             dx_ = torch.empty_like(x)
             dres_ = torch.empty_like(x) if (ctx.has_res and ctx.lazy_res is None) else None
+            word_ = math_mode.new_word(dev) if ctx.split else None
             with torch.cuda.device(dev):
-                _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
-                                                _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot_[2]), _lib.ptr(tot_[3]),
-                                                mode, None, None, _lib.ptr(dx_), _lib.ptr(dres_),
-                                                _lib.current_stream(dev)), "bn_bwd_apply")
-            return tot_, dx_, dres_
+                if word_ is not None:
+                    # split16 mode: dx is the incoming gradient of the temporal conv's data-gradient kernel
+                    _lib.check(lib.p2r_bn_bwd_apply_amax(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
+                                                         _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot_[2]),
+                                                         _lib.ptr(tot_[3]), _lib.ptr(dx_), _lib.ptr(dres_), _lib.ptr(word_),
+                                                         _lib.current_stream(dev)), "bn_bwd_apply_amax")
+                    math_mode.announce(dx_, word_)
+                else:
+                    _lib.check(lib.p2r_bn_bwd_apply(N, C, L, _lib.ptr(dy), _lib.ptr(mask), _lib.ptr(x), _lib.ptr(mean),
+                                                    _lib.ptr(invstd), _lib.ptr(kscale), _lib.ptr(tot_[2]), _lib.ptr(tot_[3]),
+                                                    mode, None, None, _lib.ptr(dx_), _lib.ptr(dres_),
+                                                    _lib.current_stream(dev)), "bn_bwd_apply")
+            return tot_, dx_, dres_, word_
 
         if side_ok and SIDE_INLINE:
-            tot, dx, dres = apply_pass()
+            tot, dx, dres, word = apply_pass()
         elif side_ok:
             # dy and the sums were complete at `ready` (recorded right behind the graph conv's data-gradient launch), but
             # this stream still has that op's weight- and adjacency-gradient kernels queued in front of us: ~2 ms of
@@ -241,15 +260,15 @@ class _FusedBNAct(Function):
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             side.wait_event(ready)
             with torch.cuda.stream(side):
-                tot, dx, dres = apply_pass()
+                tot, dx, dres, word = apply_pass()
                 done = torch.cuda.Event()
                 done.record(side)
             main.wait_event(done)
-            for t_ in (tot, dx, dres):
+            for t_ in (tot, dx, dres, word):
                 if t_ is not None:
                     t_.record_stream(main)                    # allocated from the side stream's pool, consumed here
         else:
-            tot, dx, dres = apply_pass()
+            tot, dx, dres, word = apply_pass()
         if ctx.lazy_res is not None:
             ctx.lazy_res.mask, ctx.lazy_res.grad_ptr, ctx.lazy_res.grad_version = mask, dy.data_ptr(), dy._version
             dres = dy

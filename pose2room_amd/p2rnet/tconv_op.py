@@ -17,7 +17,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from . import bn_op
+from . import bn_op, math_mode
 
 _N_BLOCKS = 256
 FUSE_DZ = True       # BatchNorm-backward apply inside the weight-gradient launch (53 joints, 3 taps); tests switch it off
@@ -32,6 +32,52 @@ def _permute_taps(W3):
 
 def _tconv2_able(W3, V):
     return W3.shape[0] in (1, 3) and V == 53
+
+
+class SplitTaps(object):
+    """Operands of the split16 temporal conv (csrc/stgcn_tconvh.hip): `wh` fp16 [2 parts][3 taps][2][4][64][8] = the parts
+    of 2^S W in the kernel's A-operand order, `winv` device float [1] = 2^-S."""
+    __slots__ = ('wh', 'winv')
+
+    def __init__(self, wh, winv):
+        self.wh, self.winv = wh, winv
+
+
+def split_taps(W3):
+    """W3 [..., 3 taps][64 co][64 ci] fp32 (leading batch dimensions allowed: one scale per leading index) ->
+    (wh [..., 2, 3, 2, 4, 64, 8] fp16, winv [..., 1] fp32):
+    wh[part][tap][ks][w][16 kg + r][i] = part of 2^S W3[tap][16 w + r][32 ks + 8 kg + i]."""
+    lead = W3.shape[:-3]
+    s, inv = math_mode.weight_scale(W3, dims=(-3, -2, -1))
+    p, q = math_mode.split_parts(W3.detach() * s)
+    n = len(lead)
+
+    def order(a):       # (..., tap, w, r, ks, kg, i) -> (..., tap, ks, w, kg, r, i)
+        a = a.reshape(*lead, 3, 4, 16, 2, 4, 8)
+        return a.permute(*range(n), n, n + 3, n + 1, n + 4, n + 2, n + 5).reshape(*lead, 3, 2, 4, 64, 8)
+    return torch.stack([order(p), order(q)], dim=n).contiguous(), inv.reshape(*lead, 1).contiguous()
+
+
+def _tconvh_able(taps, x):
+    """shapes the split16 kernel takes (anything else runs on the exact kernels in either mode)"""
+    return taps == 3 and x.shape[1] == 64 and x.shape[3] == 53 and x.shape[2] % 16 == 0 and x.shape[0] > 0
+
+
+def _tconvh(x, scale, shift, st, bias, want_stats=False, bwd=None, x_word=None):
+    """`_tconv` on the split16 kernel; st = SplitTaps; x_word = range word of x (data gradient) or None (forward)."""
+    N, C, T, V = x.shape
+    out = torch.empty_like(x)
+    chunk = 64 if T % 64 == 0 else (32 if T % 32 == 0 else 16)
+    part = None
+    if want_stats:      # one partial per workgroup = per (sample, chunk of frames)
+        part = torch.empty((N * (T // chunk), C, 3 if bwd is None else 2), dtype=torch.float32, device=x.device)
+    bz, bfin = (bwd[0], bwd[1].contiguous()) if bwd is not None else (None, None)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().p2r_stgcn_tconvh_forward(
+            N, T, V, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(st.wh), _lib.ptr(st.winv), _lib.ptr(bias),
+            _lib.ptr(out), _lib.ptr(part), None, _lib.ptr(bz), _lib.ptr(bfin), _lib.ptr(x_word),
+            _lib.current_stream(x.device)), "stgcn_tconvh_forward")
+    return (out, part) if want_stats else out
 
 
 def _tconv(x, scale, shift, W3, bias, want_stats=False, bwd=None, Wp=None):
@@ -104,7 +150,16 @@ class _BNReLUTConv(Function):
         elif wp_f is not None:
             assert taps == 3 and z.shape[3] == 53 and wp_b is not None
             W3 = None
-            out = _tconv(z, fin[2], fin[3], None, bias.contiguous() if bias is not None else None, want_stats, Wp=wp_f)
+            if isinstance(wp_f, SplitTaps):        # split16 mode (gcn_op.prepare_chain handed over fp16 operand parts)
+                out = _tconvh(z, fin[2], fin[3], wp_f, bias.contiguous() if bias is not None else None, want_stats)
+            else:
+                out = _tconv(z, fin[2], fin[3], None, bias.contiguous() if bias is not None else None, want_stats, Wp=wp_f)
+            ctx.save_for_backward(z, fin)
+        elif math_mode.split16() and _tconvh_able(taps, z):
+            W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
+            out = _tconvh(z, fin[2], fin[3], SplitTaps(*split_taps(W3)), bias.contiguous() if bias is not None else None,
+                          want_stats)
+            wp_b = SplitTaps(*split_taps(W3.flip(0).transpose(1, 2)))                # data gradient: tap p' = W[2 - p']^T
             ctx.save_for_backward(z, fin)
         else:
             W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
@@ -137,7 +192,15 @@ class _BNReLUTConv(Function):
         W3T = W3.flip(0).transpose(1, 2).contiguous() if wp_b is None else None
         need_sums = ctx.train or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         part = None
-        if need_sums and (wp_b is not None or _tconv2_able(W3T, V)):
+        split = isinstance(wp_b, SplitTaps)
+        if split:
+            # split16: the incoming gradient is lifted into fp16's range by a power of two from its range word
+            word = math_mode.range_word(du)
+            if need_sums:
+                dh, part = _tconvh(du, None, None, wp_b, None, want_stats=True, bwd=(z, fin), x_word=word)
+            else:
+                dh = _tconvh(du, None, None, wp_b, None, x_word=word)
+        elif need_sums and (wp_b is not None or _tconv2_able(W3T, V)):
             # the reduction pass of the BatchNorm backward leaves through the data-gradient kernel's epilogue
             dh, part = _tconv(du, None, None, W3T, None, want_stats=True, bwd=(z, fin), Wp=wp_b)
         else:
@@ -164,7 +227,14 @@ class _BNReLUTConv(Function):
             taps = ctx.taps
             part = torch.empty((_N_BLOCKS, 64, 64, taps), dtype=torch.float32, device=dev)
             bpart = torch.empty((_N_BLOCKS, 64), dtype=torch.float32, device=dev) if ctx.has_bias else None
-            if FUSE_DZ and taps == 3 and V == 53:
+            if FUSE_DZ and taps == 3 and V == 53 and split:
+                # ... and, in split16 mode, leaves the range word of dz for the graph conv's gradient kernels
+                word = math_mode.new_word(dev)
+                _lib.check(lib.p2r_stgcn_tconv_weight_grad_dz_amax(
+                    N, T, V, taps, _lib.ptr(z), _lib.ptr(fin), _lib.ptr(du), _lib.ptr(dh), _lib.ptr(m12), _lib.ptr(dz),
+                    _N_BLOCKS, _lib.ptr(part), _lib.ptr(bpart), _lib.ptr(word), st), "stgcn_tconv_weight_grad_dz_amax")
+                math_mode.announce(dz, word)
+            elif FUSE_DZ and taps == 3 and V == 53:
                 # the BatchNorm-backward apply pass rides on the weight-gradient kernel's tile staging (it holds z)
                 _lib.check(lib.p2r_stgcn_tconv_weight_grad_dz(N, T, V, taps, _lib.ptr(z), _lib.ptr(fin), _lib.ptr(du),
                                                               _lib.ptr(dh), _lib.ptr(m12), _lib.ptr(dz), _N_BLOCKS,

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_identity():
     l = _lib.lib()
-    assert l.p2r_abi_version() == _lib.ABI_VERSION == 2
+    assert l.p2r_abi_version() == _lib.ABI_VERSION == 3
     assert l.p2r_build_arch() == b"gfx950"
 
 

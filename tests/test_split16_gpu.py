@@ -1,0 +1,182 @@
+"""GPU: the opt-in split16 arithmetic of the ST-GCN kernels (csrc/split16.h, math_mode) against float64 and against the
+exact-fp32 kernels: every split kernel must be at most 1.5x as far from float64 as the exact kernel is on the same inputs
+(plus a floor of 2e-7 of range, the rounding of the stored fp32 result itself), over the range cases that fp16 operands
+make interesting: gradients of magnitude 1e-6 and 1e+3, tiles whose fp16 residuals are all subnormal, exact fp16 ties."""
+import copy
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+V = 53
+FLOOR = 2e-7
+
+
+def _rel(a, ref):
+    return (a.double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-300)
+
+
+def _conv64(h, W3, bias=None):
+    """float64 (3,1) convolution: h (N,64,T,V), W3 [tap][co][ci]"""
+    w = W3.double().permute(1, 2, 0).unsqueeze(-1)
+    return torch.nn.functional.conv2d(h.double(), w, bias.double() if bias is not None else None, padding=(1, 0))
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 1000, 4099, 1 << 20])
+def test_absmax_bits(dev, n):
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import math_mode
+    g = torch.Generator().manual_seed(n)
+    buf = (torch.randn(n + 1, generator=g) * 3).to(dev)
+    for x in (buf[:n], buf[1:]):                      # 16-byte aligned and not
+        before = math_mode.FALLBACK_PASSES
+        word = math_mode.range_word(x)
+        assert math_mode.FALLBACK_PASSES == before + 1
+        want = x.abs().max() if x.numel() else torch.zeros((), device=dev)
+        assert word.view(torch.float32).item() == want.item()
+    if n:
+        x = buf[:n].clone(); x[n // 2] = float('nan')
+        bits = math_mode.range_word(x).item() & 0x7fffffff
+        assert (bits >> 23) == 255 and (bits & 0x7fffff) != 0          # a NaN pattern: "no scale"
+
+
+def test_range_word_announced_only_for_the_very_tensor(dev):
+    from pose2room_amd.p2rnet import math_mode
+    x = torch.randn(1000, device=dev)
+    w = math_mode.new_word(dev); w.fill_(123)
+    math_mode.announce(x, w)
+    assert math_mode.range_word(x, keep=True) is w
+    assert math_mode.range_word(x) is w
+    assert math_mode.range_word(x) is not w                              # consumed
+    math_mode.announce(x, w)
+    x.add_(1.0)                                                          # another version of the buffer
+    assert math_mode.range_word(x) is not w
+    math_mode.reset()
+
+
+def _tconv_inputs(N, T, seed, gmag=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 64, T, V, generator=g)
+    if gmag is not None:
+        x = x * gmag
+    W3 = torch.randn(3, 64, 64, generator=g) / 8
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    bias = torch.randn(64, generator=g)
+    return x, W3, scale, shift, bias
+
+
+@pytest.mark.parametrize("N,T", [(2, 16), (3, 64), (1, 32), (2, 48), (1, 80), (4, 256), (3, 1024)])
+def test_tconvh_forward_vs_float64_and_exact(dev, N, T):
+    """forward: BatchNorm affine + ReLU on the input, bias, (count, mean, M2) statistics of the result"""
+    from pose2room_amd.p2rnet import bn_op, tconv_op
+    x, W3, scale, shift, bias = (t.to(dev) for t in _tconv_inputs(N, T, 100 + T))
+    ref = _conv64(torch.relu(x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)), W3, bias)
+    exact, epart = tconv_op._tconv(x, scale, shift, W3, bias, want_stats=True)
+    st = tconv_op.SplitTaps(*tconv_op.split_taps(W3))
+    got, part = tconv_op._tconvh(x, scale, shift, st, bias, want_stats=True)
+    e_split, e_exact = _rel(got, ref), _rel(exact, ref)
+    assert e_split <= 1.5 * e_exact + FLOOR, (e_split, e_exact)
+    assert _rel(got, exact.double()) <= 4e-6
+    # statistics of the STORED values, as the exact kernel's epilogue gives them
+    M = N * T * V
+    mean, var, _ = bn_op.moments(part, M)
+    want_mean, want_var = got.double().mean(dim=(0, 2, 3)), got.double().var(dim=(0, 2, 3), unbiased=False)
+    assert (mean - want_mean).abs().max().item() <= 1e-6 * got.abs().max().item()
+    assert ((var - want_var).abs() / want_var).max().item() <= 1e-5
+    assert part.shape[0] == N * (T // (64 if T % 64 == 0 else 32 if T % 32 == 0 else 16))
+    assert float(part[..., 0].sum(0)[0]) == M
+
+
+@pytest.mark.parametrize("gmag", [1e-6, 1.0, 1e3])
+@pytest.mark.parametrize("N,T", [(2, 16), (3, 64), (2, 1024)])
+def test_tconvh_data_gradient_range(dev, N, T, gmag):
+    """plain form (the data gradient's) with the sums of the BatchNorm + ReLU backward, on gradients of magnitude
+    1e-6 .. 1e+3: the range word puts each of them at the same place in fp16's range"""
+    from pose2room_amd.p2rnet import math_mode, tconv_op
+    du, W3, scale, shift, _ = (t.to(dev) for t in _tconv_inputs(N, T, 7 + T, gmag))
+    z = torch.randn(N, 64, T, V, device=dev)
+    mean, invstd = torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5
+    fin = torch.stack([mean, invstd, scale, shift]).contiguous()
+    ref = _conv64(du, W3)
+    exact, epart = tconv_op._tconv(du, None, None, W3, None, want_stats=True, bwd=(z, fin))
+    st = tconv_op.SplitTaps(*tconv_op.split_taps(W3))
+    got, part = tconv_op._tconvh(du, None, None, st, None, want_stats=True, bwd=(z, fin), x_word=math_mode.range_word(du))
+    e_split, e_exact = _rel(got, ref), _rel(exact, ref)
+    assert e_split <= 1.5 * e_exact + FLOOR, (gmag, e_split, e_exact)
+    # the two sums, from the stored result
+    gate = (z.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) > 0
+    gq = got.double() * gate
+    s1 = gq.sum(dim=(0, 2, 3))
+    s2 = (gq * (z.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)).sum(dim=(0, 2, 3))
+    tot = part.double().sum(0)
+    scale_ = gq.abs().sum(dim=(0, 2, 3)).max().item()
+    assert (tot[:, 0] - s1).abs().max().item() <= 1e-5 * scale_
+    assert (tot[:, 1] - s2).abs().max().item() <= 3e-5 * scale_
+    # without a range word a 1e-6 gradient sits in fp16's subnormals: the word is what makes the split work
+    if gmag == 1e-6:
+        raw = tconv_op._tconvh(du, None, None, st, None)
+        assert _rel(raw, ref) > 100 * e_split
+
+
+def test_tconvh_subnormal_residuals_and_fp16_ties(dev):
+    """(a) one large element fixes the scale, everything else is so small that its fp16 residual is subnormal: the error
+    stays an ABSOLUTE 2^-25 of the range (fixed-point behaviour), below the exact kernel's.  (b) operands at exact fp16
+    ties (x = k + 2^-11 patterns): p + q must reproduce x -- with identity taps the result equals the input bit for bit."""
+    from pose2room_amd.p2rnet import math_mode, tconv_op
+    N, T = 2, 64
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(N, 64, T, V, generator=g) * 1e-5).to(dev)
+    x[0, 0, 0, 0] = 4.0
+    W3 = (torch.randn(3, 64, 64, generator=g) / 8).to(dev)
+    st = tconv_op.SplitTaps(*tconv_op.split_taps(W3))
+    ref = _conv64(x, W3)
+    got = tconv_op._tconvh(x, None, None, st, None, x_word=math_mode.range_word(x))
+    exact = tconv_op._tconv(x, None, None, W3, None)
+    assert _rel(got, ref) <= 1.5 * _rel(exact, ref) + FLOOR
+    small = torch.ones_like(ref, dtype=torch.bool); small[0, :, 0:2, 0] = False     # outputs the large element does not reach
+    assert (got.double() - ref)[small].abs().max().item() <= 1e-9                   # ~1e-5-sized outputs: absolute, not 2^-11 relative
+    # (b)
+    k = torch.randint(1024, 2048, (N, 64, T, V), generator=g).float()
+    x = ((k + 0.5) / 1024).to(dev)               # in [1, 2): fp16 spacing 2^-10 -- every value halfway between two fp16 numbers
+    ident = torch.zeros(3, 64, 64); ident[1] = torch.eye(64)
+    st = tconv_op.SplitTaps(*tconv_op.split_taps(ident.to(dev)))
+    got = tconv_op._tconvh(x, None, None, st, None, x_word=math_mode.range_word(x))
+    assert torch.equal(got, x)
+
+
+@pytest.mark.parametrize("N,T", [(2, 64), (3, 48), (2, 1024)])
+def test_bn_relu_tconv_module_in_split16_mode(dev, N, T):
+    """the op the model calls, forward + backward under `math_mode.use('split16')`, against the float64 module chain and
+    against the exact mode: every gradient within 1.5x the exact mode's distance from float64"""
+    from pose2room_amd.p2rnet import math_mode, tconv_op
+    torch.manual_seed(N * 10 + T)
+    bn_ref = torch.nn.BatchNorm2d(64).to(dev)
+    conv_ref = torch.nn.Conv2d(64, 64, (3, 1), (1, 1), (1, 0)).to(dev)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.5, 0.5)
+    z = torch.randn(N, 64, T, V, device=dev) * 1.5 + 0.3
+    go = torch.randn(N, 64, T, V, device=dev) * 1e-4
+    res = {}
+    for m in ('exact', 'split16'):
+        bn, conv = copy.deepcopy(bn_ref).train(), copy.deepcopy(conv_ref)
+        zn = z.clone().requires_grad_(True)
+        with math_mode.use(m):
+            u = tconv_op.bn_relu_tconv(zn, bn, conv)
+            u.backward(go)
+        res[m] = (u.detach(), zn.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad)
+    bn, conv = copy.deepcopy(bn_ref).double().train(), copy.deepcopy(conv_ref).double()
+    zr = z.double().clone().requires_grad_(True)
+    pre = bn(zr)
+    ur = conv(torch.relu(pre))
+    ur.backward(go.double())
+    want = (ur.detach(), zr.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad)
+    decided = (pre.detach().abs() > 1e-5)
+    for i, what in enumerate(("u", "dz", "dW", "dbias", "dgamma", "dbeta")):
+        a, b, r = res['split16'][i].double(), res['exact'][i].double(), want[i]
+        if what == "dz":
+            a, b, r = a * decided, b * decided, r * decided
+        es, ee = _rel(a, r), _rel(b, r)
+        assert es <= 1.5 * ee + 1e-6, (what, es, ee)
+    math_mode.reset()
