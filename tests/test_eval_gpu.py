@@ -52,26 +52,43 @@ def test_parse_predictions_from_reference_endpoints(dev, tag, B, T):
 
 @pytest.mark.parametrize("tag,B,T", [('g3u', 1, 768), ('g3f', 2, 512)])
 def test_parse_predictions_2d_nms_branch(dev, tag, B, T):
-    """`use_3d_nms: False` (ap_helper.py:198-214 -> nms_2d_faster on the (x, z) extents): keep masks equal to the
-    reference's on the reference's own end points, at the configured threshold and at selective ones, both overlap
-    definitions (G5b, tests/golden/make_nms2d_golden.py)."""
-    from pose2room_amd.net_utils import ap_helper
+    """`use_3d_nms: False` (ap_helper.py:198-214 -> nms_2d_faster on the (x, z) extents), against the masks the
+    reference's parse_predictions gives on its own end points (G5b, tests/golden/make_nms2d_golden.py):
+    (1) through our parse_predictions at the configured threshold, both overlap definitions;
+    (2) at thresholds where the suppression is selective (57-252 of 128-256 boxes survive) a keep mask is a function of
+        IoU comparisons whose margins are below the one-ulp differences between device and libm exp / atan2 / cos in
+        the corners -- there the 2-D boxes are built from the reference's RECORDED corners and scores exactly as
+        ap_helper.py:201-207 builds them, and `nms_2d_faster` must return the reference's mask bit for bit."""
+    from pose2room_amd.net_utils import ap_helper, nms
     from pose2room_amd.p2rnet import P2RConfig, default_config
     from pose2room_amd.p2rnet.synthetic import make_batch
     z = np.load(G)
     z2 = np.load(os.path.join(os.path.dirname(G), 'g5b_nms2d.npz'))
     data = make_batch(B, T, seed=100 + T, device=dev)
     ep = _endpoints_from_golden(z, tag, dev)
+    ep['objectness_scores'] = torch.from_numpy(z2[f'{tag}_objectness_scores']).to(dev)     # de-tied scores, see the script
+    for old in (False, True):
+        cfg = P2RConfig(default_config('test', data={'num_frames': T},
+                                       test={'remove_far_box': False, 'use_3d_nms': False, 'use_old_type_nms': old,
+                                             'nms_iou': 0.25}), device=dev)
+        assert cfg.eval_config['use_3d_nms'] is False
+        eval_dict, _ = ap_helper.parse_predictions(ep, data, cfg.eval_config)
+        want = z2[f'{tag}_pred_mask_2d_25_{int(old)}']
+        assert eval_dict['pred_mask'].dtype == np.uint8
+        assert np.array_equal(eval_dict['pred_mask'], want), (tag, old, int(eval_dict['pred_mask'].sum()), int(want.sum()))
+    corners, prob = z2[f'{tag}_pred_corners_3d'], z2[f'{tag}_obj_prob']
+    K = corners.shape[1]
     for iou in (0.25, 0.7, 0.9, 0.97):
         for old in (False, True):
-            cfg = P2RConfig(default_config('test', data={'num_frames': T},
-                                           test={'remove_far_box': False, 'use_3d_nms': False, 'use_old_type_nms': old,
-                                                 'nms_iou': iou}), device=dev)
-            assert cfg.eval_config['use_3d_nms'] is False
-            eval_dict, _ = ap_helper.parse_predictions(ep, data, cfg.eval_config)
             want = z2[f'{tag}_pred_mask_2d_{int(round(iou * 100))}_{int(old)}']
-            assert eval_dict['pred_mask'].dtype == np.uint8
-            assert np.array_equal(eval_dict['pred_mask'], want), (tag, iou, old, int(eval_dict['pred_mask'].sum()), int(want.sum()))
+            for i in range(B):
+                b2 = np.zeros((K, 5))
+                b2[:, 0], b2[:, 2] = corners[i, :, :, 0].min(1), corners[i, :, :, 0].max(1)
+                b2[:, 1], b2[:, 3] = corners[i, :, :, 2].min(1), corners[i, :, :, 2].max(1)
+                b2[:, 4] = prob[i]
+                mask = np.zeros(K, dtype=np.uint8)
+                mask[nms.nms_2d_faster(b2, iou, old)] = 1
+                assert np.array_equal(mask, want[i]), (tag, iou, old, i, int(mask.sum()), int(want[i].sum()))
 
 
 # ---- decision-level comparison of end-to-end keep masks -------------------------------------------------------------

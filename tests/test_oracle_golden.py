@@ -56,6 +56,26 @@ def test_g2_nms_matches_reference(oracle):
                 assert oracle.nms_2d(cases.boxes_xz(boxes), thr, old) == z[f"pick2d_{tag}"].tolist()
 
 
+def test_g5b_2d_nms_masks_match_reference(oracle):
+    """The reference's `use_3d_nms: False` keep masks (ap_helper.py:198-214) from its own recorded corners and scores:
+    the 2-D oracle (nms.py:7-39) reproduces them at every threshold / overlap definition of the fixture."""
+    z2 = np.load(os.path.join(G, "g5b_nms2d.npz"))
+    for tag, B in (("g3u", 1), ("g3f", 2)):
+        corners, prob = z2[f"{tag}_pred_corners_3d"], z2[f"{tag}_obj_prob"]
+        K = corners.shape[1]
+        for iou in (0.25, 0.7, 0.9, 0.97):
+            for old in (False, True):
+                want = z2[f"{tag}_pred_mask_2d_{int(round(iou * 100))}_{int(old)}"]
+                for i in range(B):
+                    b2 = np.zeros((K, 5))
+                    b2[:, 0], b2[:, 2] = corners[i, :, :, 0].min(1), corners[i, :, :, 0].max(1)
+                    b2[:, 1], b2[:, 3] = corners[i, :, :, 2].min(1), corners[i, :, :, 2].max(1)
+                    b2[:, 4] = prob[i]
+                    mask = np.zeros(K, dtype=np.uint8)
+                    mask[oracle.nms_2d(b2, iou, old)] = 1
+                    assert np.array_equal(mask, want[i]), (tag, iou, old, i)
+
+
 def test_g6_ext_ops_stable(oracle):
     z = np.load(os.path.join(G, "g6_ext_ops.npz"))
     E = oracle.OracleExt
