@@ -658,7 +658,8 @@ int p2r_stgcn_tconv_weight_grad_dz_amax(int N, int T, int V, int taps, const flo
 
 /* The (3,1) temporal convolution of p2r_stgcn_tconv3_forward (taps = 3, V = 53, T % 16 == 0) in split16 arithmetic
  * (csrc/stgcn_tconvh.hip).  x, scale, shift, bias, out, bwd_z, bwd_fin as there.
- *   Wh    fp16 [2 parts][3 taps][2][4][64 lanes][8]: the parts of 2^S_w W[tap][co][ci] in A-operand order,
+ *   Wh    fp16 [3 parts][3 taps][2][4][64 lanes][8]: the parts (w1 = fp16(w), w2 = fp16(w - w1), 2^-11 w1) of
+ *         w = 2^S_w W[tap][co][ci] in A-operand order,
  *         Wh[part][tap][ks][w][16 kg + r][i] = part of 2^S_w W[tap][16 w + r][32 ks + 8 kg + i]   (16-byte aligned)
  *   winv  device float: 2^-S_w
  *   x_amax range word of x (the data gradient's incoming gradient) or NULL (forward: the activation relu(x*scale+shift)
@@ -670,6 +671,28 @@ int p2r_stgcn_tconvh_forward(int N, int T, int V, const float *x, const float *s
                              const void *Wh, const float *winv, const float *bias, float *out, float *stats_partial,
                              int *n_partials, const float *bwd_z, const float *bwd_fin, const unsigned *x_amax,
                              void *stream);
+
+/* The fused graph convolution of p2r_stgcn_gcn3_forward in split16 arithmetic (csrc/stgcn_gcn3h_body.h): statically
+ * scheduled for the P2RNet skeleton like the third generation, with plane PAIRS as the MFMA's K dimension (16 channels x
+ * two planes).  p2r_stgcn_gcn3h_signature(form) = signature of the neighbour-table pattern the schedule of form 0
+ * (column lists, forward) / 1 (row lists, data gradient) was generated for; p2r_stgcn_gcn3h_pairs(form, out[2 * 6])
+ * returns the number of pairs and writes them (second plane -1 = none).  T % 16 == 0, tensors 16-byte aligned.
+ *   Wh    fp16 [6 pairs][4 phases][3 parts][4 m][64 lanes][8]: the parts (w1, w2, 2^-11 w1) of 2^S_w [W_a | W_b] in
+ *         A-operand order,
+ *         Wh[pair][ph][part][m][16 kg + r][i] = part of 2^S_w W_{plane (i < 4 ? a : b)}[16 m + r][16 ph + kg + 4 (i & 3)]
+ *         (forward: W_k [c][ci]; data gradient: W_k^T)
+ *   winv  device float 2^-S_w;  coef [ltot][53] f32 as for p2r_stgcn_gcn3_forward (the kernel scales it by 2^S_x)
+ *   x_amax / dz_amax: range word of the operand tensor (NULL: scale 1)
+ *   stats_partial [*n_partials][64][3] (optional) as p2r_stgcn_gcn3_forward's forward statistics.
+ * The data gradient adds `addend` (NULL: nothing) where the bytes of `addend_mask` are non-zero (NULL: everywhere). */
+unsigned long long p2r_stgcn_gcn3h_signature(int form);
+int p2r_stgcn_gcn3h_pairs(int form, int *pairs);
+int p2r_stgcn_gcn3h_forward(int N, int T, int V, int K, int ltot, const float *x, const void *Wh, const float *winv,
+                            const float *coef, const float *bias_cv, float *z, float *stats_partial, int *n_partials,
+                            const unsigned *x_amax, void *stream);
+int p2r_stgcn_gcn3h_data_gradient(int N, int T, int V, int K, int ltot, const float *dz, const void *Wh,
+                                  const float *winv, const float *coef, const float *addend,
+                                  const unsigned char *addend_mask, float *dx, const unsigned *dz_amax, void *stream);
 
 #ifdef __cplusplus
 }

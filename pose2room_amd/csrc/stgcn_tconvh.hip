@@ -52,14 +52,16 @@ __global__ __launch_bounds__(256, 2) void tconvh_kernel(
   p2r_split_scale(x_amax, xs, xinv);
   const float inv = xinv * winv[0];
 
-  // A operands: 2^S_w W[tap][co = 16 wave + r][ci = 32 ks + 8 kg + i], split on the host: Wh[part][tap][ks][wave][lane]
-  p2r_h8 A1[3][2], A2[3][2];
+  // A operands: 2^S_w W[tap][co = 16 wave + r][ci = 32 ks + 8 kg + i], split on the host: Wh[part][tap][ks][wave][lane],
+  // parts (w1, w2, w1' = 2^-11 w1: the partner of the operand's scaled residual, split16.h)
+  p2r_h8 A1[3][2], A2[3][2], A1s[3][2];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       A1[p][ks] = Wh[(((0 * 3 + p) * 2 + ks) * 4 + wv) * 64 + lane];
       A2[p][ks] = Wh[(((1 * 3 + p) * 2 + ks) * 4 + wv) * 64 + lane];
+      A1s[p][ks] = Wh[(((2 * 3 + p) * 2 + ks) * 4 + wv) * 64 + lane];
     }
   float bq[4];
 #pragma unroll
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void tconvh_kernel(
           const p2r_h8 b1 = *reinterpret_cast<const p2r_h8 *>(fr + (((0 * 2 + ks) * 4 + kg) * 64 + 16 * nt + r) * 8);
           const p2r_h8 b2 = *reinterpret_cast<const p2r_h8 *>(fr + (((1 * 2 + ks) * 4 + kg) * 64 + 16 * nt + r) * 8);
           // the two small products in their own accumulator (added to the large one once, at the end)
-          lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[p][ks], b2, lo[nt], 0, 0, 0);
+          lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1s[p][ks], b2, lo[nt], 0, 0, 0);
           lo[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[p][ks], b1, lo[nt], 0, 0, 0);
           hi[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[p][ks], b1, hi[nt], 0, 0, 0);
         }

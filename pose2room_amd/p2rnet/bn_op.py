@@ -107,6 +107,13 @@ def _apply(x, scale, shift, res, relu, want_mask=False):
     return (y, mask) if want_mask else y
 
 
+# Inspection hook for the ReLU gates behind a BatchNorm: callable(bn_module, x, scale, shift, res) called with the
+# BatchNorm's input, its per-channel affine constants (batch or running statistics folded in) and the residual (or None)
+# right before the fused kernel evaluates relu(x * scale + shift + res); it may adjust x IN PLACE.  The parity tests use it
+# to find the gates whose pre-activation is within rounding of zero and pin them to the reference's recorded state
+# (tests/test_model_cpu.py: GateForcer) -- one flipped gate moves the gradients upstream of it by far more than rounding.
+GATE_HOOK = None
+
 OVERLAP_APPLY = True      # BatchNorm-backward apply pass on a side stream under the graph conv's gradient kernels
 OVERLAP_REDUCE = True     # ... and its reduction pass too (the data-gradient kernel then runs without the sums epilogue)
 SIDE_INLINE = False       # tests only: the very same launches as with the overlap on, but issued on the MAIN stream -- what
@@ -313,6 +320,8 @@ def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None, lazy_res=Non
     if bn.training:
         part = _stats_partial(x.contiguous()) if stats is None else stats
         fin = finalize(part, x.numel() // x.shape[1], bn)
+        if GATE_HOOK is not None and relu:
+            GATE_HOOK(bn, x, fin[2], fin[3], res)
         y = _FusedBNAct.apply(x, bn.weight, bn.bias, res, fin, relu, link, lazy_res)
         if link is not None and relu:
             y._p2r_bn_link = link
@@ -320,4 +329,6 @@ def fused_bn_act(x, bn, res=None, relu=True, stats=None, link=None, lazy_res=Non
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     shift = bn.bias - bn.running_mean * scale
+    if GATE_HOOK is not None and relu:
+        GATE_HOOK(bn, x, scale.detach(), shift.detach(), res)
     return _EvalBNAct.apply(x, scale, shift, res, relu)

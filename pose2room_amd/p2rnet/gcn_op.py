@@ -16,7 +16,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from . import bn_op, gcn_tables
+from . import bn_op, gcn_tables, math_mode
 
 _N_BLOCKS = 256     # persistent workgroups of the reduction kernels (one per CU)
 
@@ -44,6 +44,8 @@ class GraphTables:
         # third generation (csrc/stgcn_gcn3.hip): statically scheduled for ONE pattern, the P2RNet skeleton's; taken
         # when the signatures of both table forms equal the ones the library was generated for
         self._gen3 = None
+        self._gen3h = None
+        self._pairs = (None, None)
         self._dev = {}
 
     @property
@@ -61,6 +63,34 @@ class GraphTables:
     def gen2(self):
         """True when the second-generation kernels (static work streams) serve this adjacency pattern."""
         return self.stream_c is not None
+
+    @property
+    def gen3h(self):
+        """True when the split16 kernels (csrc/stgcn_gcn3h_body.h: schedules generated for ONE pattern, like the third
+        generation) serve this adjacency pattern; then `pairs_c` / `pairs_r` hold their plane pairs."""
+        if self._gen3h is None:
+            ok = False
+            if self.gen3:
+                lib = _lib.lib()
+                ok = (gcn_tables.pattern_signature(self.nbr_c, self.gidx_c, self.Lk_c) == lib.p2r_stgcn_gcn3h_signature(0)
+                      and gcn_tables.pattern_signature(self.nbr_r, self.gidx_r, self.Lk_r) == lib.p2r_stgcn_gcn3h_signature(1))
+                if ok:
+                    buf = (ctypes.c_int * 32)()
+                    n = lib.p2r_stgcn_gcn3h_pairs(0, buf)
+                    pc = [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+                    n = lib.p2r_stgcn_gcn3h_pairs(1, buf)
+                    self._pairs = (pc, [(buf[2 * i], buf[2 * i + 1]) for i in range(n)])
+            self._gen3h = ok
+        return self._gen3h
+
+    @property
+    def pairs_c(self):
+        """plane pairs of the split16 forward schedule (None when `gen3h` is false)"""
+        return self._pairs[0] if self.gen3h else None
+
+    @property
+    def pairs_r(self):
+        return self._pairs[1] if self.gen3h else None
 
     def on(self, device):
         key = str(device)
@@ -154,16 +184,84 @@ def _gcn2_forward(x, Wp, coef, stream, bias_cv, tables, want_stats=False, addend
     return (z, part) if want_stats else z
 
 
+class SplitPlanes(object):
+    """Operands of the split16 graph conv (csrc/stgcn_gcn3h_body.h): `wh` fp16 [6 pairs][4 phases][3 parts][4][64][8] =
+    the parts (w1, w2, 2^-11 w1) of 2^S [W_a | W_b] in the kernel's A-operand order, `winv` device float [1] = 2^-S."""
+    __slots__ = ('wh', 'winv')
+
+    def __init__(self, wh, winv):
+        self.wh, self.winv = wh, winv
+
+
+def split_planes(W, pairs):
+    """W [..., K][64 rows][64 cols] fp32 (leading batch dimensions allowed: one scale per leading index), pairs = the
+    schedule's plane pairs -> (wh [..., P, 4, 3 parts, 4, 64, 8] fp16, winv [..., 1] fp32):
+    wh[pair][ph][part][m][16 kg + r][i] = part of 2^S W_{plane (i < 4 ? a : b)}[16 m + r][16 ph + kg + 4 (i & 3)]."""
+    lead = W.shape[:-3]
+    n = len(lead)
+    s, inv = math_mode.weight_scale(W, dims=(-3, -2, -1))
+    Ws = W.detach() * s
+    zero = torch.zeros_like(Ws[..., 0, :, :])
+    sel = torch.stack([torch.stack([Ws[..., a, :, :], Ws[..., b, :, :] if b >= 0 else zero], dim=n) for a, b in pairs],
+                      dim=n)                                                  # (..., P, 2, 64, 64)
+    parts = math_mode.split_parts(sel)
+    P = len(pairs)
+
+    def order(a):       # (..., P, h, m, r, ph, q, kg) -> (..., P, ph, m, kg, r, h, q)
+        a = a.reshape(*lead, P, 2, 4, 16, 4, 4, 4)
+        return a.permute(*range(n), n, n + 4, n + 2, n + 6, n + 3, n + 1, n + 5).reshape(*lead, P, 4, 4, 64, 8)
+    return torch.stack([order(a) for a in parts], dim=n + 2).contiguous(), inv.reshape(*lead, 1).contiguous()
+
+
+def _gen3h_able(x, tables):
+    """shapes the split16 graph-conv kernels take (anything else runs on the exact kernels in either mode)"""
+    return (USE_GEN3 and tables.gen3h and x.shape[0] > 0 and x.shape[2] % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def _gcn3h_forward(x, sp, coef, bias_cv, tables, want_stats, x_word):
+    N, C, T, V = x.shape
+    z = torch.empty_like(x)
+    part = torch.empty((min(N * (T // 16), 256), C, 3), dtype=torch.float32, device=x.device) if want_stats else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().p2r_stgcn_gcn3h_forward(
+            N, T, V, tables.K, coef.shape[0], _lib.ptr(x), _lib.ptr(sp.wh), _lib.ptr(sp.winv), _lib.ptr(coef),
+            _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part), None, _lib.ptr(x_word), _lib.current_stream(x.device)),
+            "stgcn_gcn3h_forward")
+    return (z, part) if want_stats else z
+
+
+def _gcn3h_data_gradient(dz, sp, coef, tables, addend, addend_mask, dz_word):
+    N, C, T, V = dz.shape
+    dx = torch.empty_like(dz)
+    with torch.cuda.device(dz.device):
+        _lib.check(_lib.lib().p2r_stgcn_gcn3h_data_gradient(
+            N, T, V, tables.K, coef.shape[0], _lib.ptr(dz), _lib.ptr(sp.wh), _lib.ptr(sp.winv), _lib.ptr(coef),
+            _lib.ptr(addend), _lib.ptr(addend_mask), _lib.ptr(dx), _lib.ptr(dz_word), _lib.current_stream(dz.device)),
+            "stgcn_gcn3h_data_gradient")
+    return dx
+
+
 class _GraphConv(Function):
     @staticmethod
     def forward(ctx, x, weight, coef_c, coef_r, bias_cv, tables, want_stats=False, with_residual=False,
-                bn_link=None, wp_f=None, wp_b=None, lazy_res=None):
+                bn_link=None, wp_f=None, wp_b=None, lazy_res=None, split=None):
         # weight (K*64, 64): plane k rows = output channels of plane k
         dev = x.device
         t = tables.on(dev)
         x = x.contiguous()
         W = weight.contiguous()
-        if tables.gen2:         # second-generation kernel (csrc/stgcn_gcn2.hip)
+        ctx.split = ctx.x_word = None
+        if split is None and math_mode.split16() and _gen3h_able(x, tables):
+            W3 = W.view(tables.K, 64, 64)
+            split = (SplitPlanes(*split_planes(W3, tables.pairs_c)),
+                     SplitPlanes(*split_planes(W3.transpose(1, 2), tables.pairs_r)))
+        if split is not None and _gen3h_able(x, tables):
+            # split16 mode: two-part fp16 products (csrc/stgcn_gcn3h_body.h); x's range word stays with the op -- x is an
+            # operand of the weight- and adjacency-gradient kernels again
+            ctx.split = split
+            ctx.x_word = math_mode.range_word(x)
+            out = _gcn3h_forward(x, split[0], coef_c.contiguous(), bias_cv.contiguous(), tables, want_stats, ctx.x_word)
+        elif tables.gen2:         # second-generation kernel (csrc/stgcn_gcn2.hip)
             out = _gcn2_forward(x, wp_f if wp_f is not None else permute_planes(W.view(tables.K, 64, 64)),
                                 coef_c.contiguous(), t['stream_c'], bias_cv.contiguous(), tables, want_stats, form=0)
         else:
@@ -204,7 +302,23 @@ class _GraphConv(Function):
         dx = dW = dcoef_r = dbias = None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
-            if tables.gen2:
+            dz_word = math_mode.range_word(dz, keep=True) if ctx.split is not None else None
+            if ctx.split is not None:
+                link = ctx.bn_link
+                use_link = link is not None and link.intact() and link.u.shape == x.shape
+                # (the sums epilogue of the exact kernel does not exist here: the BatchNorm backward in front runs its
+                # own reduction pass -- on the side stream under the gradient kernels below when the overlap is on)
+                ad = dres.contiguous() if dres is not None else None
+                if dres_mask is not None and dres_mask.data_ptr() % 4 != 0:
+                    ad, dres_mask = ad * (dres_mask != 0), None
+                dx = _gcn3h_data_gradient(dz, ctx.split[1], coef_r.contiguous(), tables, ad, dres_mask, dz_word)
+                if use_link:
+                    link.partials = None
+                    link.grad_ptr, link.grad_version = dx.data_ptr(), dx._version
+                    link.ready = torch.cuda.Event()
+                    link.ready.record(torch.cuda.current_stream(dev))
+                dres = None
+            elif tables.gen2:
                 link = ctx.bn_link
                 use_link = link is not None and link.intact() and link.u.shape == x.shape
                 # the sums either leave through this kernel's epilogue, or -- when the BatchNorm backward will run its
@@ -284,7 +398,7 @@ class _GraphConv(Function):
             if dres_mask is not None:
                 dres = dres * (dres_mask != 0)
             dx = dres if dx is None else dx + dres
-        return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None, None
+        return dx, dW, None, dcoef_r, dbias, None, None, None, None, None, None, None, None
 
 
 def grad_kernel_mfma_flops(tables, batch, frames):
@@ -344,7 +458,7 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
     w2 = weight.reshape(K * 64, 64)
     if prepared is not None:
         return _GraphConv.apply(x, w2, prepared.coef_c, prepared.coef_r, prepared.bias_cv, tables, want_stats,
-                                with_residual, bn_link, prepared.gcn_wp_f, prepared.gcn_wp_b, lazy_res)
+                                with_residual, bn_link, prepared.gcn_wp_f, prepared.gcn_wp_b, lazy_res, prepared.gcn_split)
     coef_c = gcn_tables.coefficients(Aeff.detach(), t['gidx_c'])      # forward lists (values only)
     coef_r = gcn_tables.coefficients(Aeff, t['gidx_r'])               # backward lists; carries the gradient to Aeff
     if bias is not None:
@@ -357,10 +471,10 @@ def graph_conv(x, weight, bias, Aeff, tables, want_stats=False, with_residual=Fa
 
 class BlockParams(object):
     """One st_gcn_block's share of `prepare_chain`."""
-    __slots__ = ('Aeff', 'coef_c', 'coef_r', 'bias_cv', 'gcn_wp_f', 'gcn_wp_b', 'tcn_wp_f', 'tcn_wp_b')
+    __slots__ = ('Aeff', 'coef_c', 'coef_r', 'bias_cv', 'gcn_wp_f', 'gcn_wp_b', 'tcn_wp_f', 'tcn_wp_b', 'gcn_split')
 
 
-def prepare_chain(blocks, A, importances, tables):
+def prepare_chain(blocks, A, importances, tables, frames=None):
     """The small per-block parameter transforms of the fused path, done for ALL blocks of an ST-GCN stack at once:
     `A * edge_importance`, the two coefficient tables, the bias table, and the kernel-order copies of the graph-conv
     planes and temporal-conv taps (forward and data-gradient forms).  Per block these are ~25 launches of a few
@@ -395,11 +509,26 @@ def prepare_chain(blocks, A, importances, tables):
         tcn_f = Wt.view(B, 4, 16, 4, 4, 4, 3).permute(0, 6, 3, 1, 5, 2, 4).contiguous()    # (b,tap,ph,m,g,r,s)
         # data gradient: tap p' uses W[2 - p']^T
         tcn_b = Wt.flip(-1).view(B, 4, 4, 4, 4, 16, 3).permute(0, 6, 1, 4, 3, 5, 2).contiguous()   # rows = (ph,s,g)
+        # split16 mode (math_mode; whole 16-frame tiles of the 53-joint skeleton only): the weights once per step as
+        # two-part fp16 operands in the split kernels' lane order, one power-of-two scale per block
+        split = (math_mode.split16() and tables.gen3h and V == 53 and frames is not None and frames % 16 == 0)
+        if split:
+            from . import tconv_op
+            math_mode.reset()
+            gsf, gsf_inv = split_planes(W, tables.pairs_c)
+            gsb, gsb_inv = split_planes(W.transpose(-1, -2), tables.pairs_r)
+            W3 = Wt.permute(0, 3, 1, 2)                                          # (B, tap, c, ci)
+            tsf, tsf_inv = tconv_op.split_taps(W3)
+            tsb, tsb_inv = tconv_op.split_taps(W3.flip(1).transpose(-1, -2))    # data gradient: tap p' = W[2 - p']^T
     out = []
     A_b, cc, cr, bc = Aeff.unbind(0), coef_c.unbind(0), coef_r.unbind(0), bias_cv.unbind(0)
     for i in range(B):
         p = BlockParams()
         p.Aeff, p.coef_c, p.coef_r, p.bias_cv = A_b[i], cc[i], cr[i], bc[i]
         p.gcn_wp_f, p.gcn_wp_b, p.tcn_wp_f, p.tcn_wp_b = gcn_f[i], gcn_b[i], tcn_f[i], tcn_b[i]
+        p.gcn_split = None
+        if split:
+            p.gcn_split = (SplitPlanes(gsf[i], gsf_inv[i]), SplitPlanes(gsb[i], gsb_inv[i]))
+            p.tcn_wp_f, p.tcn_wp_b = tconv_op.SplitTaps(tsf[i], tsf_inv[i]), tconv_op.SplitTaps(tsb[i], tsb_inv[i])
         out.append(p)
     return out

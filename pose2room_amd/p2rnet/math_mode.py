@@ -102,7 +102,10 @@ def weight_scale(w, dims):
 
 
 def split_parts(ws):
-    """ws fp32 (already scaled into fp16's range) -> (p, q) fp16 with p = fp16(ws), q = fp16(ws - p)."""
+    """ws fp32 weights (already scaled into fp16's range) -> (p, q, ps) fp16: p = fp16(ws), q = fp16(ws - p), and
+    ps = 2^-11 p -- the partner of a runtime operand's residual, which the kernels keep scaled by 2^11 (csrc/split16.h)."""
     p = ws.to(torch.float16)
-    q = (ws - p.to(torch.float32)).to(torch.float16)
-    return p, q
+    pf = p.to(torch.float32)
+    q = (ws - pf).to(torch.float16)
+    ps = (pf * 2.0 ** -11).to(torch.float16)
+    return p, q, ps

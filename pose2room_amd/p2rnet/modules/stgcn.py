@@ -152,7 +152,7 @@ class STGCN(nn.Module):
         if tables is not None and tables.gen2 and all(b.chainable(x, self.A) for b in blocks):
             # fused train-mode path: the per-block parameter transforms are computed for all blocks at once
             from ..gcn_op import prepare_chain
-            for gcn, prep in zip(blocks, prepare_chain(blocks, self.A, self.edge_importance, tables)):
+            for gcn, prep in zip(blocks, prepare_chain(blocks, self.A, self.edge_importance, tables, frames=x.shape[2])):
                 x, _ = gcn(x, prep.Aeff, prepared=prep)
         else:
             for gcn, importance in zip(blocks, self.edge_importance):

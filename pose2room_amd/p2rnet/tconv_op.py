@@ -35,8 +35,8 @@ def _tconv2_able(W3, V):
 
 
 class SplitTaps(object):
-    """Operands of the split16 temporal conv (csrc/stgcn_tconvh.hip): `wh` fp16 [2 parts][3 taps][2][4][64][8] = the parts
-    of 2^S W in the kernel's A-operand order, `winv` device float [1] = 2^-S."""
+    """Operands of the split16 temporal conv (csrc/stgcn_tconvh.hip): `wh` fp16 [3 parts][3 taps][2][4][64][8] = the parts
+    (w1, w2, 2^-11 w1) of 2^S W in the kernel's A-operand order, `winv` device float [1] = 2^-S."""
     __slots__ = ('wh', 'winv')
 
     def __init__(self, wh, winv):
@@ -45,17 +45,17 @@ class SplitTaps(object):
 
 def split_taps(W3):
     """W3 [..., 3 taps][64 co][64 ci] fp32 (leading batch dimensions allowed: one scale per leading index) ->
-    (wh [..., 2, 3, 2, 4, 64, 8] fp16, winv [..., 1] fp32):
+    (wh [..., 3 parts, 3, 2, 4, 64, 8] fp16, winv [..., 1] fp32), parts = (w1, w2, 2^-11 w1) (math_mode.split_parts):
     wh[part][tap][ks][w][16 kg + r][i] = part of 2^S W3[tap][16 w + r][32 ks + 8 kg + i]."""
     lead = W3.shape[:-3]
     s, inv = math_mode.weight_scale(W3, dims=(-3, -2, -1))
-    p, q = math_mode.split_parts(W3.detach() * s)
+    parts = math_mode.split_parts(W3.detach() * s)
     n = len(lead)
 
     def order(a):       # (..., tap, w, r, ks, kg, i) -> (..., tap, ks, w, kg, r, i)
         a = a.reshape(*lead, 3, 4, 16, 2, 4, 8)
         return a.permute(*range(n), n, n + 3, n + 1, n + 4, n + 2, n + 5).reshape(*lead, 3, 2, 4, 64, 8)
-    return torch.stack([order(p), order(q)], dim=n).contiguous(), inv.reshape(*lead, 1).contiguous()
+    return torch.stack([order(a) for a in parts], dim=n).contiguous(), inv.reshape(*lead, 1).contiguous()
 
 
 def _tconvh_able(taps, x):
@@ -335,9 +335,13 @@ def bn_relu_tconv(z, bn, conv, stats=None, want_stats=False, wp=None, add_ct=Non
     if bn.training:
         part = bn_op._stats_partial(z.contiguous()) if stats is None else stats
         fin = bn_op.finalize(part, z.numel() // z.shape[1], bn)     # also updates the running statistics
+        if bn_op.GATE_HOOK is not None:
+            bn_op.GATE_HOOK(bn, z, fin[2], fin[3], None)
         wp_f, wp_b = wp if wp is not None else (None, None)
         return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, True, want_stats, wp_f, wp_b, add_ct)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     scale = bn.weight * invstd
     fin = torch.stack([bn.running_mean, invstd, scale, bn.bias - bn.running_mean * scale]).detach()
+    if bn_op.GATE_HOOK is not None:
+        bn_op.GATE_HOOK(bn, z, fin[2], fin[3], None)
     return _BNReLUTConv.apply(z, bn.weight, bn.bias, fin, conv.weight, conv.bias, False, want_stats, None, None, add_ct)

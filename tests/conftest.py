@@ -26,3 +26,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["exact", "split16"])
+def mathmode(request):
+    """Runs a test once per arithmetic mode of the ST-GCN kernels (pose2room_amd.p2rnet.math_mode): the exact-fp32 default
+    and the opt-in split16 mode.  The golden tests (G3-G10) take this fixture: same fixtures, same tolerances, both modes."""
+    from pose2room_amd.p2rnet import math_mode
+    with math_mode.use(request.param):
+        yield request.param
+    math_mode.reset()

@@ -179,7 +179,7 @@ def _check_keep_masks(oracle, what, thr, ours, ref, got_mask, ref_mask, ours_non
           f'(all within {MARGIN:g} of their threshold in the reference run)')
 
 
-def test_generate_end_to_end(dev, oracle):
+def test_generate_end_to_end(dev, oracle, mathmode):
     """Whole `generate` on the GPU (network + parsing + NMS) against the reference run."""
     from pose2room_amd.p2rnet.synthetic import make_batch
     z = np.load(G)
@@ -196,7 +196,7 @@ def test_generate_end_to_end(dev, oracle):
     assert len(eval_dict['batch_gt_map_cls']) == 2
 
 
-def test_far_box_filter_matches_delaunay_reference(dev, oracle):
+def test_far_box_filter_matches_delaunay_reference(dev, oracle, mathmode):
     """remove_far_box=True: the closed-form point-in-box test vs the reference's
     Delaunay hull test (G5, captured with the same weights and inputs)."""
     from pose2room_amd.p2rnet.synthetic import make_batch
@@ -216,7 +216,7 @@ def test_far_box_filter_matches_delaunay_reference(dev, oracle):
                       eval_dict['pred_mask'], z['g5far_pred_mask'], ne_o, ne_r, margin_r)
 
 
-def test_test_loop_metrics(dev):
+def test_test_loop_metrics(dev, mathmode):
     """test_epoch-style loop: Tester.test_step over batches -> loss meters + APCalculator per IoU threshold.
     The metric of the pipeline's own lists must equal the metric of the same lists evaluated pair by pair."""
     from pose2room_amd.net_utils import eval_det, box_util

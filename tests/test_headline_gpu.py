@@ -98,7 +98,7 @@ def test_backbone_at_bench_shape_fused_vs_plain(dev):
     assert not bad, bad
 
 
-def test_train_step_at_bench_shape(dev):
+def test_train_step_at_bench_shape(dev, mathmode):
     """One full train step at bs=32, T=1024: finite losses, parameters move, and the fused detection loss equals its
     torch composition on the very tensors of that step."""
     import math
@@ -123,7 +123,7 @@ def test_train_step_at_bench_shape(dev):
     assert v['losses_finite'] and v['seed_inds_equal']
 
 
-def test_forward_and_loss_at_config1_shape(dev):
+def test_forward_and_loss_at_config1_shape(dev, mathmode):
     """BASELINE configs[1] at its full size (bs=8, T=512, J=53): P2RNet forward + detection loss on the HIP path
     (fused backbone, vote / proposal heads on the job-list kernels, fused vote aggregation, fused loss) against the same
     weights through the plain torch chain (reference formulation of the graph conv, nn.BatchNorm, nn.Conv1d heads, the
@@ -253,7 +253,7 @@ def _check_forward_and_loss(z, tag, ep, loss, tol, tol_loss):
 
 
 @pytest.mark.parametrize('tag', ['g10a', 'g10b'])
-def test_g10_forward_and_loss_vs_reference(dev, tag):
+def test_g10_forward_and_loss_vs_reference(dev, tag, mathmode):
     """BASELINE configs[1] (bs=8, T=512) and configs[2] (bs=32, T=1024): P2RNet.forward + BoxNetDetectionLoss on the HIP
     path, train-mode BatchNorm, against the REFERENCE's own run of the same weights / batch / mixture noise
     (/root/reference/models/p2rnet/modules/network.py:75-106, models/loss.py:152-189, imported in the build
@@ -281,7 +281,7 @@ def _packed_err(z, key, got):
     return np.abs(g - ref), float(z[key + '_sum'][2])
 
 
-def test_g10c_backbone_backward_vs_reference(dev):
+def test_g10c_backbone_backward_vs_reference(dev, mathmode):
     """bs=8, T=1024, train-mode BatchNorm: seeded cotangents on (vote_xyz, vote_features) back-propagated through the
     backbone + voting on the HIP kernels; EVERY backbone / voting parameter gradient against the reference's autograd
     (stgcn_layers.py:50-67,399-439) evaluated in FLOAT64.  Two fp32 evaluations of these gradients differ visibly, for
@@ -339,7 +339,7 @@ def test_g10c_backbone_backward_vs_reference(dev):
     assert ours <= 2 * theirs, (ours, theirs)
 
 
-def test_g10e_eval_bn_step_vs_reference(dev):
+def test_g10e_eval_bn_step_vs_reference(dev, mathmode):
     """bs=8, T=1024 with every BatchNorm on running statistics: the whole step end to end at the north star's 1e-4
     -- end points, 10 losses, d total / d pred_center, ~130 parameter gradients.  The gradient at the seam is compared
     element-wise EXCEPT that the max-pool of the vote aggregation routes a ball's gradient to the arg-max vote: where
@@ -396,7 +396,7 @@ def test_g10e_eval_bn_step_vs_reference(dev):
     assert max(v for n, v in worst.items() if behind(n)) <= tol
 
 
-def test_g10f_long_sequence_eval_vs_reference(dev, oracle):
+def test_g10f_long_sequence_eval_vs_reference(dev, oracle, mathmode):
     """BASELINE configs[4]'s stress length through the EVALUATION path (test_epoch.py:18-46 on one batch): bs=2, T=2048,
     `generate(data, eval=True)` -- network, prediction parsing, far-box filter, NMS on device, per-class lists -- the
     loss dict of `Tester.test_step` and `APCalculator.compute_metrics()` at IoU 0.25 / 0.5, against the imported

@@ -52,4 +52,38 @@ if 'tconv' in what:
         print(f'tconv {name}: exact {timed(fe):.3f} ms, split16 {timed(fs):.3f} ms, difference {d:.2e} of range', flush=True)
     print(f'absmax pass: {timed(lambda: math_mode.range_word(du)):.3f} ms')
 if 'gcn' in what or 'gcn_dw' in what:
-    import dev_split16_gcn  # noqa: F401
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    A = Graph().A
+    K = A.shape[0]
+    tables = gcn_op.GraphTables(A)
+    t = tables.on(dev)
+    assert tables.gen3h
+    W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
+    Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
+    cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+    bias = torch.randn(64, V, generator=g).to(dev)
+    xa = torch.relu(x + 0.3)
+    dz = x * 1e-4
+if 'gcn' in what:
+    spf = gcn_op.SplitPlanes(*gcn_op.split_planes(W, tables.pairs_c))
+    spb = gcn_op.SplitPlanes(*gcn_op.split_planes(W.transpose(1, 2), tables.pairs_r))
+    wpf, wpb = gcn_op.permute_planes(W), gcn_op.permute_planes(W.transpose(1, 2).contiguous())
+    xw, dw_ = math_mode.range_word(xa), math_mode.range_word(dz)
+    add = x * 1e-4
+    mask = (torch.rand(N, 64, T, V, generator=g) > 0.5).to(torch.uint8).to(dev)
+    rows = [
+        ('forward + statistics', lambda: gcn_op._gcn2_forward(xa, wpf, cc, t['stream_c'], bias, tables, True, form=0),
+         lambda: gcn_op._gcn3h_forward(xa, spf, cc, bias, tables, True, xw)),
+        ('data gradient + masked addend',
+         lambda: gcn_op._gcn2_forward(dz, wpb, cr, t['stream_r'], None, tables, addend=add, form=1, addend_mask=mask),
+         lambda: gcn_op._gcn3h_data_gradient(dz, spb, cr, tables, add, mask, dw_)),
+        ('data gradient, plain', lambda: gcn_op._gcn2_forward(dz, wpb, cr, t['stream_r'], None, tables, form=1),
+         lambda: gcn_op._gcn3h_data_gradient(dz, spb, cr, tables, None, None, dw_)),
+    ]
+    for name, fe, fs in rows:
+        a, b = fe(), fs()
+        a, b = (a[0] if isinstance(a, tuple) else a), (b[0] if isinstance(b, tuple) else b)
+        d = (a - b).abs().max().item() / a.abs().max().item()
+        print(f'gcn {name}: exact {timed(fe):.3f} ms, split16 {timed(fs):.3f} ms, difference {d:.2e} of range', flush=True)
