@@ -29,6 +29,10 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   step_roofline-- the whole step: MFMA FLOPs issued per step (stored PMC profile) over this run's step time;
   ddp          -- N > 1 only: per-rank step times, and the step time with the gradient all-reduce switched off
                   (`no_sync`) next to the one with it = the all-reduce time that is NOT hidden under the backward pass;
+  split16      -- the SAME K steps in the opt-in split16 arithmetic of the ST-GCN kernels (pose2room_amd.p2rnet.math_mode:
+                  two-part fp16 MFMA products, fp32 accumulation): value / ms_per_step / verify, and the split kernels
+                  against the 16-bit MFMA roof (2.5 PFLOP/s dense) on the 16-bit MFMA FLOPs they issue.  Labelled,
+                  never the headline: `value`, `dtype` and `roofline` above are the exact-fp32 path;
   kernels      -- event-timed durations of the pointnet2 / loss HIP kernels at the P2RNet shapes (`GBps_l2_assisted`:
                   algorithmic bytes / time of a gather whose 17 MB source stays in L2 / MALL -- not an HBM rate);
   cpu_baseline -- the same host model on the host cores with the CPU oracle behind
@@ -52,6 +56,7 @@ if ROOT not in sys.path:
 # imported reference); linear in T.
 _GFLOP_PER_SAMPLE = {512: 99.44, 768: 147.94, 1024: 196.44, 2048: 390.45}
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense BF16 / FP16 MFMA (same table; the 5 PF headline figure includes 2:1 sparsity)
 
 
 def gflop_per_sample(T):
@@ -151,7 +156,7 @@ _TIMED = {
 def issued_mfma_flops(batch, frames):
     """MFMA FLOPs each ST-GCN kernel ISSUES per launch at this shape (v_mfma_f32_16x16x4_f32 = 2048 FLOP), counted
     from the work tables the kernels run on -- units with an empty neighbour list are skipped, so this is less than
-    the dense operator (`dense_equivalent`, the figure of rounds 1-2).  Cross-checked against the
+    the dense operator.  Cross-checked against the
     SQ_VALU_MFMA_BUSY_CYCLES x 64 of profiles/*_graphconv_mfma_util.json."""
     import numpy as np
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
@@ -220,12 +225,79 @@ def mfma_rooflines(trainer, batch, batch_size, frames, steps=3):
             'achieved': round(tf, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
             'traffic': int(traffic['bytes_per_launch'] * scale) if traffic else None,
+            'traffic_source': 'stored PMC measurement (profiles/r5_gcn3_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE passes of this kernel at bs=32, T=1024, scaled by the column count), not a counter read in this run',
             'ms_per_launch': round(ms, 4), 'timing': f'HIP events around each of the {n_g2 // steps} launches per step inside '
                                                       f'{steps} instrumented train steps',
             'flops_per_launch': fl, 'flops': 'MFMA FLOPs issued (454 of 583 (plane, joint) units forward, 369 data gradient)',
             'ms_forward': round(per['gcn_forward'][0], 4) if 'gcn_forward' in per else None,
             'ms_data_gradient': round(per['gcn_data_gradient'][0], 4) if 'gcn_data_gradient' in per else None,
             'algorithmic_bytes_per_launch': 2 * 4 * 64 * cols}
+    return roof, rows
+
+
+# split16 mode: the entry points the ST-GCN blocks call instead (include/p2r_hip.h, "opt-in split16 arithmetic"); the
+# weight gradient of the temporal conv (HBM-bound with the BatchNorm-backward apply pass on board) stays on the exact
+# kernel in this mode
+_TIMED16 = {
+    'p2r_stgcn_gcn3h_forward': lambda a: None if _null(a[10]) else 'gcn_forward',
+    'p2r_stgcn_gcn3h_data_gradient': lambda a: 'gcn_data_gradient',
+    'p2r_stgcn_tconvh_forward': lambda a: None if _null(a[9]) else ('tconv_data_gradient' if _null(a[4]) else 'tconv_forward'),
+    'p2r_stgcn_gcn3_coef_grad': lambda a: 'gcn_coef_grad (exact kernel)',
+    'p2r_stgcn_gcn3h_coef_grad': lambda a: 'gcn_coef_grad',
+    'p2r_stgcn_gcn3_weight_grad': lambda a: 'gcn_weight_grad (exact kernel)',
+    'p2r_stgcn_gcn3h_weight_grad': lambda a: 'gcn_weight_grad',
+    'p2r_stgcn_tconv_weight_grad_dz_amax': lambda a: 'tconv_weight_grad (exact kernel)',
+    'p2r_absmax_bits': lambda a: 'range_word_fallback_pass',
+}
+
+
+def split16_rooflines(trainer, batch, batch_size, frames, steps=3):
+    """In-step durations of the split16 kernels and their rate on the 16-bit MFMA FLOPs they ISSUE
+    (v_mfma_f32_16x16x32_f16 = 16,384 FLOP; three per fp32-equivalent product) against the dense fp16 MFMA peak."""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    tables = gcn_op.GraphTables(Graph().A)
+    tiles16 = batch_size * (frames // 16)
+    issued = {}
+    if tables.gen3h:
+        uc, ur = gcn_op.split_unit_counts(tables)
+        issued['gcn_forward'] = uc * 12 * 4 * 16384.0 * tiles16          # (pair, joint) units x 12 MFMAs x 4 channel phases
+        issued['gcn_data_gradient'] = ur * 12 * 4 * 16384.0 * tiles16
+    issued['tconv_forward'] = issued['tconv_data_gradient'] = 4 * 72 * 16384.0 * batch_size * frames   # 4 waves x 72 per frame
+    if tables.gen3h:        # adjacency gradient: 6 MFMAs per live (plane, joint) unit of the row lists, 16-frame tile and row phase
+        import numpy as np
+        g_ = tables.gidx_r.numpy()
+        lofs_ = np.concatenate([[0], np.cumsum(tables.Lk_r)])
+        live_ = sum(int((g_[lofs_[k]:lofs_[k + 1]] >= 0).any(0).sum()) for k in range(tables.K))
+        issued['gcn_coef_grad'] = live_ * 4 * 6 * 16384.0 * tiles16
+    if tables.gen3h:        # 56 live (plane, 8-joint group) units x 24 MFMAs x 2 column halves per 4-frame tile
+        issued['gcn_weight_grad'] = gcn_op.split_weight_grad_units(tables) * 24 * 2 * 16384.0 * batch_size * (frames // 4)
+    with LaunchTimer(_lib.lib(), _TIMED16) as lt:
+        for _ in range(steps):
+            trainer.train_step(dict(batch))
+        per = lt.summary()
+    rows = {}
+    for tag in sorted(per):
+        ms, n = per[tag]
+        if tag in issued:
+            tf = issued[tag] / ms / 1e9
+            rows[tag] = {'ms_in_step': round(ms, 4), 'launches_per_step': n // steps, 'mfma16_flops_issued': issued[tag],
+                         'tflops': round(tf, 1), 'frac': round(tf / FP16_MFMA_PEAK_TFLOPS, 4)}
+        else:
+            rows[tag] = {'ms_in_step': round(ms, 4), 'launches_per_step': round(n / steps, 2)}
+    g = [t for t in ('gcn_forward', 'gcn_data_gradient') if t in per and t in issued]
+    roof = None
+    if g:
+        n_g = sum(per[t][1] for t in g)
+        ms = sum(per[t][0] * per[t][1] for t in g) / n_g
+        fl = sum(issued[t] * per[t][1] for t in g) / n_g
+        tf = fl / ms / 1e9
+        roof = {'bound': 'mfma', 'kernel': 'gcn3h kernels (split16 graph conv: 6 forward + 6 data-gradient launches/step)',
+                'achieved': round(tf, 1), 'peak': FP16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / FP16_MFMA_PEAK_TFLOPS, 4),
+                'traffic': None, 'ms_per_launch': round(ms, 4), 'flops_per_launch': fl,
+                'flops': '16-bit MFMA FLOPs issued (v_mfma_f32_16x16x32_f16; 3 per fp32-equivalent product)',
+                'timing': f'HIP events around each launch inside {steps} instrumented split16 train steps'}
     return roof, rows
 
 
@@ -374,6 +446,7 @@ def main():
     ap.add_argument('--frames', type=int, default=1024, help='T (BASELINE: 1024)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-microbench', action='store_true')
+    ap.add_argument('--no-split16', action='store_true', help='skip the labelled split16 sub-measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -492,13 +565,49 @@ def main():
             with trainer.net.no_sync():
                 return trainer.train_step(dict(batch))
         step_no_sync()
-        elapsed_ns, _, step_ms_ns = timed(step_no_sync)
+        # the two forms back to back, twice, in the same thermal / clock state (a difference against the headline block,
+        # timed minutes earlier, is mostly noise: each number is a max over ranks with ~1 % spread)
+        rounds = []
+        for _ in range(2):
+            e_sync, _, _ = timed(step)
+            e_ns, _, _ = timed(step_no_sync)
+            rounds.append((e_sync / args.steps * 1e3, e_ns / args.steps * 1e3))
+        exposed = [a - b for a, b in rounds]
         ddp_info = {'rank_step_ms_median': per_rank, 'rank_spread_ms': round(max(per_rank) - min(per_rank), 3),
-                    'ms_per_step_no_sync': round(elapsed_ns / args.steps * 1e3, 3),
-                    'allreduce_exposed_ms_per_step': round((elapsed - elapsed_ns) / args.steps * 1e3, 3),
-                    'how': 'K more steps under DDP.no_sync() (no gradient all-reduce) against the timed K steps; the '
-                           '80-byte logging all-reduce is in both', 'gradient_bytes_per_step': 8176132,
+                    'ms_per_step_no_sync': round(min(b for _, b in rounds), 3),
+                    'ms_per_step_sync_same_block': round(min(a for a, _ in rounds), 3),
+                    'allreduce_exposed_ms_per_step': round(max(0.0, min(exposed)), 3),
+                    'allreduce_exposed_rounds_ms': [round(e, 3) for e in exposed],
+                    'how': '2 x (K steps with the gradient all-reduce, K steps under DDP.no_sync()) back to back; exposed = '
+                           'the smaller difference, clamped at 0 (noise floor ~1 % of a step); the 80-byte logging '
+                           'all-reduce is in both', 'gradient_bytes_per_step': 8176132,
                     'backend': dist.get_backend()}
+
+    # ---- the same steps in the opt-in split16 arithmetic (every rank runs them: they contain the gradient all-reduce).
+    # After everything the exact path needs; the mode is switched back before the line is printed.
+    split16 = None
+    if not args.no_split16 and args.frames % 16 == 0:
+        from pose2room_amd.p2rnet import math_mode
+        math_mode.set_mode('split16')
+        try:
+            verify16 = verify_bench_shape(trainer, batch)
+            for _ in range(args.warmup):
+                step()
+            passes0 = math_mode.FALLBACK_PASSES
+            elapsed16, last16, step_ms16 = timed(step)
+            passes = (math_mode.FALLBACK_PASSES - passes0) / float(args.steps)
+            roof16, rows16 = split16_rooflines(trainer, batch, args.batch, args.frames)
+        finally:
+            math_mode.set_mode('exact')
+            math_mode.reset()
+        split16 = {'value': round(world * args.batch * args.steps / elapsed16, 3), 'unit': 'samples/s',
+                   'ms_per_step': round(elapsed16 / args.steps * 1e3, 3), 'step_ms': step_ms16, 'verify': verify16,
+                   'dtype': 'f32 products as three fp16 MFMA products of two-part operands (22 of 24 significand bits), '
+                            'fp32 accumulation -- ST-GCN graph conv forward / data gradient and temporal conv forward / data '
+                            'gradient; every other kernel exact fp32',
+                   'loss_total': round(float(last16['total']), 4), 'range_word_fallback_passes_per_step': passes,
+                   'roofline': roof16, 'kernels': rows16, 'speedup_vs_exact': round(elapsed / elapsed16, 4),
+                   'how': 'P2R_MATH=split16 / math_mode.set_mode; same trainer, same batch, same K and W as the headline'}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -523,6 +632,8 @@ def main():
         }
         if ddp_info:
             line['ddp'] = ddp_info
+        if split16:
+            line['split16'] = split16
         line['roofline'] = roof
         line['mfma_kernels'] = rows
         issued, src = step_mfma_issued(args.batch, args.frames)

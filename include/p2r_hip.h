@@ -694,6 +694,27 @@ int p2r_stgcn_gcn3h_data_gradient(int N, int T, int V, int K, int ltot, const fl
                                   const float *winv, const float *coef, const float *addend,
                                   const unsigned char *addend_mask, float *dx, const unsigned *dz_amax, void *stream);
 
+/* Weight gradient of the graph convolution in split16 arithmetic (csrc/stgcn_gcn3dwh.hip): the operator and the outputs of
+ * p2r_stgcn_gcn3_weight_grad -- dw_partial [n_blocks][K][64 ci][64 c] (dW_k transposed) and, optionally, dbias_partial
+ * [n_blocks][64][53] (column sums of dz: the bias-table gradient), both summed over the leading axis by the caller -- with
+ * K = 32 = (frame of a 4-frame tile) x (8 joints of a group) per MFMA.  coef [ltot][53]: the row-form coefficient table.
+ * T % 4 == 0, x / dz 16-byte aligned; x_amax / dz_amax: range words of the two operand tensors (NULL: scale 1).
+ * p2r_stgcn_gcn3h_weight_grad_signature() = signature of the row-form neighbour tables the schedule was generated for. */
+unsigned long long p2r_stgcn_gcn3h_weight_grad_signature(void);
+int p2r_stgcn_gcn3h_weight_grad(int N, int T, int V, int K, int ltot, const float *x, const float *dz, const float *coef,
+                                int n_blocks, float *dw_partial, float *dbias_partial, const unsigned *x_amax,
+                                const unsigned *dz_amax, void *stream);
+
+/* Adjacency gradient of the graph convolution in split16 arithmetic (csrc/stgcn_gcn3h_grad.hip): arguments and result of
+ * p2r_stgcn_gcn3_coef_grad; the product Y_k = W_k . x runs on two-part fp16 operands, its reduction against the gathered
+ * rows of dz stays fp32 vector arithmetic (dz needs no range word).
+ *   Wd    fp16 [K][4 ph][2 parts][2 ks][64 lanes][8]: the parts (w1, w2) of 2^S_w W_k (forward planes) in A-operand order,
+ *         Wd[k][ph][part][ks][16 kg + r][i] = part of 2^S_w W_k[16 ph + r][32 ks + 16 (i >> 2) + 4 (i & 3) + kg]
+ *   winv  device float 2^-S_w;  x_amax: range word of x (NULL: scale 1).  T % 16 == 0; x, dz, Wd 16-byte aligned. */
+int p2r_stgcn_gcn3h_coef_grad(int N, int T, int V, int K, int ltot, const float *x, const float *dz, const void *Wd,
+                              const float *winv, int n_blocks, float *dcoef_partial, const unsigned *x_amax,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

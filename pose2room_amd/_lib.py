@@ -49,7 +49,7 @@ def lib():
                                   "(make -C pose2room_amd/csrc)")
         for name in declared_symbols():
             fn = getattr(l, name)
-            if name in ("p2r_stgcn_gcn3_signature", "p2r_stgcn_gcn3h_signature"):
+            if name in ("p2r_stgcn_gcn3_signature", "p2r_stgcn_gcn3h_signature", "p2r_stgcn_gcn3h_weight_grad_signature"):
                 fn.restype = ctypes.c_uint64
             elif name not in ("p2r_build_arch",):
                 fn.restype = ctypes.c_int

@@ -72,8 +72,9 @@ class GraphTables:
             ok = False
             if self.gen3:
                 lib = _lib.lib()
+                sig_r = gcn_tables.pattern_signature(self.nbr_r, self.gidx_r, self.Lk_r)
                 ok = (gcn_tables.pattern_signature(self.nbr_c, self.gidx_c, self.Lk_c) == lib.p2r_stgcn_gcn3h_signature(0)
-                      and gcn_tables.pattern_signature(self.nbr_r, self.gidx_r, self.Lk_r) == lib.p2r_stgcn_gcn3h_signature(1))
+                      and sig_r == lib.p2r_stgcn_gcn3h_signature(1) and sig_r == lib.p2r_stgcn_gcn3h_weight_grad_signature())
                 if ok:
                     buf = (ctypes.c_int * 32)()
                     n = lib.p2r_stgcn_gcn3h_pairs(0, buf)
@@ -127,6 +128,8 @@ def permute_planes(W3):
 
 
 USE_GEN3 = True      # statically scheduled kernel for the P2RNet skeleton (tests switch it off to reach gcn2)
+SPLIT_WEIGHT_GRAD = True   # split16 mode: the weight gradient on the split kernel too (tests / A-B timing switch it off)
+SPLIT_COEF_GRAD = True     # ... and the adjacency gradient
 
 
 def _gen3_able(x, z, addend, tables, bwd=None):
@@ -213,6 +216,45 @@ def split_planes(W, pairs):
     return torch.stack([order(a) for a in parts], dim=n + 2).contiguous(), inv.reshape(*lead, 1).contiguous()
 
 
+def split_unit_counts(tables):
+    """(forward, data gradient): (plane pair, joint) units of the split16 schedules per 16-frame tile and channel phase --
+    a unit is live when either plane of the pair has a non-empty neighbour list at the joint (12 MFMAs each)."""
+    import numpy as np
+    out = []
+    for gidx, Lk, pairs in ((tables.gidx_c, tables.Lk_c, tables.pairs_c), (tables.gidx_r, tables.Lk_r, tables.pairs_r)):
+        g = gidx.numpy()
+        lofs = np.concatenate([[0], np.cumsum(Lk)])
+        live = np.stack([(g[lofs[k]:lofs[k + 1]] >= 0).any(0) for k in range(tables.K)])
+        out.append(int(sum((live[a] | (live[b] if b >= 0 else False)).sum() for a, b in pairs)))
+    return tuple(out)
+
+
+def split_planes_coef_grad(W):
+    """W [..., K][64 rows][64 cols] fp32 (forward planes; one scale per leading index) -> the A operands of the split16
+    adjacency-gradient kernel (csrc/stgcn_gcn3h_grad.hip): (wd [..., K, 4 ph, 2 parts, 2 ks, 64, 8] fp16, winv [..., 1]):
+    wd[k][ph][part][ks][16 kg + r][i] = part of 2^S W_k[16 ph + r][32 ks + 16 (i >> 2) + 4 (i & 3) + kg]."""
+    lead = W.shape[:-3]
+    n = len(lead)
+    K = W.shape[-3]
+    s, inv = math_mode.weight_scale(W, dims=(-3, -2, -1))
+    p, q, _ = math_mode.split_parts(W.detach() * s)
+
+    def order(a):       # (..., K, ph, r, ks, h, q, kg) -> (..., K, ph, ks, kg, r, h, q)
+        a = a.reshape(*lead, K, 4, 16, 2, 2, 4, 4)
+        return a.permute(*range(n), n, n + 1, n + 3, n + 6, n + 2, n + 4, n + 5).reshape(*lead, K, 4, 2, 64, 8)
+    return torch.stack([order(p), order(q)], dim=n + 2).contiguous(), inv.reshape(*lead, 1).contiguous()
+
+
+def split_weight_grad_units(tables):
+    """live (plane, group of 8 joints) units of the split16 weight-gradient schedule per 4-frame tile (24 MFMAs per unit and
+    wave, two waves -- the column halves -- per plane set)"""
+    import numpy as np
+    g = tables.gidx_r.numpy()
+    lofs = np.concatenate([[0], np.cumsum(tables.Lk_r)])
+    live = np.stack([(g[lofs[k]:lofs[k + 1]] >= 0).any(0) for k in range(tables.K)])      # [K][V]
+    return int(sum(live[k, 8 * grp:8 * grp + 8].any() for k in range(tables.K) for grp in range((tables.V + 7) // 8)))
+
+
 def _gen3h_able(x, tables):
     """shapes the split16 graph-conv kernels take (anything else runs on the exact kernels in either mode)"""
     return (USE_GEN3 and tables.gen3h and x.shape[0] > 0 and x.shape[2] % 16 == 0 and x.data_ptr() % 16 == 0)
@@ -254,7 +296,8 @@ class _GraphConv(Function):
         if split is None and math_mode.split16() and _gen3h_able(x, tables):
             W3 = W.view(tables.K, 64, 64)
             split = (SplitPlanes(*split_planes(W3, tables.pairs_c)),
-                     SplitPlanes(*split_planes(W3.transpose(1, 2), tables.pairs_r)))
+                     SplitPlanes(*split_planes(W3.transpose(1, 2), tables.pairs_r)),
+                     SplitPlanes(*split_planes_coef_grad(W3)))
         if split is not None and _gen3h_able(x, tables):
             # split16 mode: two-part fp16 products (csrc/stgcn_gcn3h_body.h); x's range word stays with the op -- x is an
             # operand of the weight- and adjacency-gradient kernels again
@@ -300,9 +343,10 @@ class _GraphConv(Function):
         N, C, T, V = x.shape
         K = tables.K
         dx = dW = dcoef_r = dbias = None
+        # split16 mode: dz is an operand of up to three split kernels below -- its range word is looked up once
+        dz_word = math_mode.range_word(dz) if ctx.split is not None else None
         if ctx.needs_input_grad[0]:
             # dX = sum_k W_k^T (dZ . A_k^T): forward kernel with transposed planes + row lists
-            dz_word = math_mode.range_word(dz, keep=True) if ctx.split is not None else None
             if ctx.split is not None:
                 link = ctx.bn_link
                 use_link = link is not None and link.intact() and link.u.shape == x.shape
@@ -359,7 +403,13 @@ class _GraphConv(Function):
                 part = torch.empty((_N_BLOCKS, K, C, C), dtype=torch.float32, device=dev)
                 # the bias-table gradient (column sums of dz) rides on the same pass over dz
                 bpart = torch.empty((_N_BLOCKS, C, V), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
-                if (USE_GEN3 and tables.gen3 and N > 0 and T % 4 == 0 and x.data_ptr() % 16 == 0
+                if ctx.split is not None and SPLIT_WEIGHT_GRAD and dz.data_ptr() % 16 == 0:
+                    # split16 mode (csrc/stgcn_gcn3dwh.hip): both operands are runtime tensors, each with its range word
+                    _lib.check(lib.p2r_stgcn_gcn3h_weight_grad(
+                        N, T, V, K, coef_r.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(coef_r.contiguous()), _N_BLOCKS,
+                        _lib.ptr(part), _lib.ptr(bpart), _lib.ptr(ctx.x_word), _lib.ptr(dz_word), st),
+                        "stgcn_gcn3h_weight_grad")
+                elif (USE_GEN3 and tables.gen3 and N > 0 and T % 4 == 0 and x.data_ptr() % 16 == 0
                         and dz.data_ptr() % 16 == 0):      # (N == 0: the first-generation kernel returns zeros)
                     # statically scheduled kernel (csrc/stgcn_gcn3_dw.hip)
                     _lib.check(lib.p2r_stgcn_gcn3_weight_grad(
@@ -379,7 +429,14 @@ class _GraphConv(Function):
                 # leave ~20 % of the (plane, 16-column) units empty, which the kernel skips
                 ltot = coef_r.shape[0]
                 part = torch.empty((_N_BLOCKS, ltot, V), dtype=torch.float32, device=dev)
-                if USE_GEN3 and tables.gen3 and T % 16 == 0 and dz.data_ptr() % 16 == 0:
+                if (ctx.split is not None and SPLIT_COEF_GRAD and T % 16 == 0 and dz.data_ptr() % 16 == 0
+                        and x.data_ptr() % 16 == 0):
+                    # split16 mode (csrc/stgcn_gcn3h_grad.hip): Y_k = W_k x on two-part fp16 operands; dz stays fp32
+                    sp = ctx.split[2]
+                    _lib.check(lib.p2r_stgcn_gcn3h_coef_grad(N, T, V, K, ltot, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(sp.wh),
+                                                             _lib.ptr(sp.winv), _N_BLOCKS, _lib.ptr(part),
+                                                             _lib.ptr(ctx.x_word), st), "stgcn_gcn3h_coef_grad")
+                elif USE_GEN3 and tables.gen3 and T % 16 == 0 and dz.data_ptr() % 16 == 0:
                     # statically scheduled kernel (csrc/stgcn_gcn3_grad.hip)
                     wp_f = ctx.wp_f if ctx.wp_f is not None else permute_planes(W.view(K, C, C))
                     _lib.check(lib.p2r_stgcn_gcn3_coef_grad(N, T, V, K, ltot, _lib.ptr(x), _lib.ptr(dz), _lib.ptr(wp_f),
@@ -517,6 +574,7 @@ def prepare_chain(blocks, A, importances, tables, frames=None):
             math_mode.reset()
             gsf, gsf_inv = split_planes(W, tables.pairs_c)
             gsb, gsb_inv = split_planes(W.transpose(-1, -2), tables.pairs_r)
+            gsd, gsd_inv = split_planes_coef_grad(W)
             W3 = Wt.permute(0, 3, 1, 2)                                          # (B, tap, c, ci)
             tsf, tsf_inv = tconv_op.split_taps(W3)
             tsb, tsb_inv = tconv_op.split_taps(W3.flip(1).transpose(-1, -2))    # data gradient: tap p' = W[2 - p']^T
@@ -528,7 +586,7 @@ def prepare_chain(blocks, A, importances, tables, frames=None):
         p.gcn_wp_f, p.gcn_wp_b, p.tcn_wp_f, p.tcn_wp_b = gcn_f[i], gcn_b[i], tcn_f[i], tcn_b[i]
         p.gcn_split = None
         if split:
-            p.gcn_split = (SplitPlanes(gsf[i], gsf_inv[i]), SplitPlanes(gsb[i], gsb_inv[i]))
+            p.gcn_split = (SplitPlanes(gsf[i], gsf_inv[i]), SplitPlanes(gsb[i], gsb_inv[i]), SplitPlanes(gsd[i], gsd_inv[i]))
             p.tcn_wp_f, p.tcn_wp_b = tconv_op.SplitTaps(tsf[i], tsf_inv[i]), tconv_op.SplitTaps(tsb[i], tsb_inv[i])
         out.append(p)
     return out

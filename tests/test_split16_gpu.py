@@ -344,3 +344,40 @@ def test_graph_conv_split16_heavy_tailed_gradient(dev, N, T):
     ws, we = _per_run_error(got, ref, k, 'split16'), _per_run_error(exact, ref, k, 'exact')
     for kk in sorted(ws):
         assert ws[kk] <= 1.5 * we[kk] + FLOOR, (kk, ws, we)
+
+
+@pytest.mark.parametrize("N,T", [(2, 80), (3, 1008)])
+def test_graph_conv_split16_weight_gradient_heavy_tailed(dev, N, T):
+    """the split16 weight gradient (both operands runtime tensors, each with its range word; bias-table gradient from the
+    same tile) on a heavy-tailed dz against float64: within 1.5x the exact kernel's error"""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables, math_mode
+    A, x, w, b, imp, go = _gcn_case(N, T, 17)
+    tables = gcn_op.GraphTables(A)
+    assert tables.gen3h
+    t = tables.on(dev)
+    K = A.shape[0]
+    Aeff = (torch.tensor(A, dtype=torch.float32) * imp).to(dev)
+    cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+    dz, k = _tail_profile(N, T, 23)
+    x, dz = (x * 3.0).to(dev), dz.to(dev)
+    U = torch.einsum('nitv,kvw->nkitw', x.double(), Aeff.double())
+    ref = torch.einsum('nctw,nkitw->kci', dz.double(), U)                    # [k][c][ci]
+    refb = dz.double().sum(dim=(0, 2))                                       # [c][v]
+    lib, st = _lib.lib(), _lib.current_stream(dev)
+    NB = 256
+    out = {}
+    for name in ('exact', 'split16'):
+        part = torch.full((NB, K, 64, 64), float('nan'), device=dev)
+        bpart = torch.full((NB, 64, V), float('nan'), device=dev)
+        if name == 'exact':
+            _lib.check(lib.p2r_stgcn_gcn3_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                      _lib.ptr(part), _lib.ptr(bpart), st), 'gcn3_weight_grad')
+        else:
+            _lib.check(lib.p2r_stgcn_gcn3h_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                       _lib.ptr(part), _lib.ptr(bpart), _lib.ptr(math_mode.range_word(x)),
+                                                       _lib.ptr(math_mode.range_word(dz)), st), 'gcn3h_weight_grad')
+        out[name] = (part.double().sum(0).transpose(1, 2), bpart.double().sum(0))
+    for i, (what, r) in enumerate((('dW', ref), ('dbias table', refb))):
+        es, ee = _rel(out['split16'][i], r), _rel(out['exact'][i], r)
+        assert es <= 1.5 * ee + FLOOR, (what, es, ee)

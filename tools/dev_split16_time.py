@@ -9,7 +9,7 @@ import torch
 from pose2room_amd.p2rnet import math_mode, tconv_op
 
 dev = torch.device('cuda:0')
-what = sys.argv[1:] or ['tconv', 'gcn', 'gcn_dw']
+what = sys.argv[1:] or ['tconv', 'gcn', 'gcn_dw', 'gcn_dc']
 N, T, V = int(os.environ.get('N', 32)), int(os.environ.get('T', 1024)), 53
 
 
@@ -51,7 +51,7 @@ if 'tconv' in what:
         d = (a - b).abs().max().item() / a.abs().max().item()
         print(f'tconv {name}: exact {timed(fe):.3f} ms, split16 {timed(fs):.3f} ms, difference {d:.2e} of range', flush=True)
     print(f'absmax pass: {timed(lambda: math_mode.range_word(du)):.3f} ms')
-if 'gcn' in what or 'gcn_dw' in what:
+if 'gcn' in what or 'gcn_dw' in what or 'gcn_dc' in what:
     from pose2room_amd.p2rnet import gcn_op, gcn_tables
     from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
     A = Graph().A
@@ -87,3 +87,49 @@ if 'gcn' in what:
         a, b = (a[0] if isinstance(a, tuple) else a), (b[0] if isinstance(b, tuple) else b)
         d = (a - b).abs().max().item() / a.abs().max().item()
         print(f'gcn {name}: exact {timed(fe):.3f} ms, split16 {timed(fs):.3f} ms, difference {d:.2e} of range', flush=True)
+if 'gcn_dw' in what:
+    import ctypes
+    from pose2room_amd import _lib
+    lib = _lib.lib()
+    xw, dw_ = math_mode.range_word(xa), math_mode.range_word(dz)
+    NB = 256
+    part = torch.empty(NB, K, 64, 64, device=dev)
+    bpart = torch.empty(NB, 64, V, device=dev)
+    st = _lib.current_stream(dev)
+
+    def fe():
+        _lib.check(lib.p2r_stgcn_gcn3_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(xa), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                  _lib.ptr(part), _lib.ptr(bpart), st), 'gcn3_weight_grad')
+        return part.sum(0), bpart.sum(0)
+
+    def fs():
+        _lib.check(lib.p2r_stgcn_gcn3h_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(xa), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                   _lib.ptr(part), _lib.ptr(bpart), _lib.ptr(xw), _lib.ptr(dw_), st), 'gcn3h_weight_grad')
+        return part.sum(0), bpart.sum(0)
+    (a, ab), (b, bb) = fe(), fs()
+    ts = timed(lambda: (part.sum(0), bpart.sum(0)))
+    print(f'gcn weight gradient (+ bias table): exact {timed(fe) - ts:.3f} ms, split16 {timed(fs) - ts:.3f} ms (kernels alone), difference '
+          f'{((a - b).abs().max() / a.abs().max()).item():.2e} / {((ab - bb).abs().max() / ab.abs().max()).item():.2e} of range', flush=True)
+if 'gcn_dc' in what:
+    from pose2room_amd import _lib
+    lib = _lib.lib()
+    xw = math_mode.range_word(xa)
+    NB = 256
+    ltot = cr.shape[0]
+    part = torch.empty(NB, ltot, V, device=dev)
+    st = _lib.current_stream(dev)
+    wpf = gcn_op.permute_planes(W)
+    spd = gcn_op.SplitPlanes(*gcn_op.split_planes_coef_grad(W))
+
+    def fe():
+        _lib.check(lib.p2r_stgcn_gcn3_coef_grad(N, T, V, K, ltot, _lib.ptr(xa), _lib.ptr(dz), _lib.ptr(wpf), NB, _lib.ptr(part), st), 'coef_grad')
+        return part.sum(0)
+
+    def fs():
+        _lib.check(lib.p2r_stgcn_gcn3h_coef_grad(N, T, V, K, ltot, _lib.ptr(xa), _lib.ptr(dz), _lib.ptr(spd.wh), _lib.ptr(spd.winv), NB,
+                                                 _lib.ptr(part), _lib.ptr(xw), st), 'coef_gradh')
+        return part.sum(0)
+    a, b = fe(), fs()
+    ts = timed(lambda: part.sum(0))
+    print(f'gcn adjacency gradient: exact {timed(fe) - ts:.3f} ms, split16 {timed(fs) - ts:.3f} ms (kernels alone), difference '
+          f'{((a - b).abs().max() / a.abs().max()).item():.2e} of range', flush=True)
