@@ -6,7 +6,8 @@ seeded synthetic dataset through P2RNet_dataloader, runs two train steps and che
   * every parameter is bit-identical on all ranks afterwards (the gradients were all-reduced),
   * the ranks saw different samples,
   * DDP reduced the gradients in the bucket layout DESIGN.md section 7 states (f32 payload in one bucket),
-  * the all-reduced gradients are bit-equal with the BatchNorm-backward passes on the side stream and inline.
+  * the all-reduced gradients are bit-equal with the BatchNorm-backward passes on the side stream and inline, in the
+    exact and in the split16 arithmetic mode.
 Rank 0 prints one JSON line."""
 import json
 import os
@@ -103,17 +104,25 @@ def main():
             return {n: p.grad.detach().clone() for n, p in trainer.net.module.named_parameters()}
         finally:
             bn_op.SIDE_INLINE = False
-    base = reduced_grads(True)
+    # ... in both arithmetic modes: in split16 mode the side-stream passes also EMIT the range words (max |dx| by atomicMax)
+    # that scale the operands of the split kernels on the main stream -- a word read before its producer had joined would
+    # change the scale, and with it the bits of every gradient upstream
+    from pose2room_amd.p2rnet import math_mode
     report = []
-    for rnd in range(3):
-        for inline in (True, False):
-            got = reduced_grads(inline)
-            differ = [n for n in base if not torch.equal(base[n], got[n])]
-            worst = max([((base[n] - got[n]).abs().max() / (base[n].abs().max() + 1e-30)).item() for n in differ] or [0.0])
-            report.append((rnd, 'main' if inline else 'side', len(differ), worst, differ[:3]))
-    assert all(r[2] == 0 for r in report), f'reduced gradients differ from the one-stream order: {report}'
+    for mode in ('exact', 'split16'):
+        with math_mode.use(mode):
+            base = reduced_grads(True)
+            for rnd in range(3):
+                for inline in (True, False):
+                    got = reduced_grads(inline)
+                    differ = [n for n in base if not torch.equal(base[n], got[n])]
+                    worst = max([((base[n] - got[n]).abs().max() / (base[n].abs().max() + 1e-30)).item() for n in differ] or [0.0])
+                    report.append((mode, rnd, 'main' if inline else 'side', len(differ), worst, differ[:3]))
+        math_mode.reset()
+    assert all(r[3] == 0 for r in report), f'reduced gradients differ from the one-stream order: {report}'
     if rank == 0:
-        print(json.dumps({'world': world, 'side_stream_equals_one_stream': True, 'backend': dist.get_backend(), 'steps': i + 1,
+        print(json.dumps({'world': world, 'side_stream_equals_one_stream': True, 'modes': ['exact', 'split16'],
+                          'backend': dist.get_backend(), 'steps': i + 1,
                           'loss_total': losses['total'],
                           'bucket_sizes': str(log.get('bucket_sizes', '')),
                           'num_buckets': int(log.get('num_buckets_reduced', -1)) if 'num_buckets_reduced' in log else None,

@@ -30,5 +30,10 @@ def test_bench_two_ranks_share_gpu():
     ddp = line['ddp']
     assert len(ddp['rank_step_ms_median']) == 2 and all(v > 0 for v in ddp['rank_step_ms_median'])
     assert ddp['ms_per_step_no_sync'] > 0 and 'allreduce_exposed_ms_per_step' in ddp and ddp['backend'] == 'gloo'
+    # the labelled split16 sub-measurement is part of rank 0's ONE line (every rank ran its steps: they contain the
+    # gradient all-reduce), with its own verification
+    s16 = line['split16']
+    assert s16['value'] > 0 and s16['ms_per_step'] > 0 and s16['verify']['losses_finite']
+    assert line['dtype'] == 'f32' and 'split16' not in line['metric']            # never the headline
     # gradients must arrive in the layout DDP's bucket views expect (no silent extra copies)
     assert 'strides' not in out.stderr, out.stderr[-2000:]

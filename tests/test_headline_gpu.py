@@ -386,12 +386,18 @@ def test_g10e_eval_bn_step_vs_reference(dev, mathmode):
     print('g10e vs reference:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in m.items()})
     for n in sorted(worst, key=worst.get, reverse=True)[:8]:
         print(f'  {worst[n]:.3e}  {n}')
-    # Parameters BEHIND the max-pool (the proposal heads) hold 1e-4.  Everything in front of it -- the shared MLP of the
-    # vote aggregation, voting, backbone -- receives its gradient through d vote_features, 1e-3 of whose entries sit on
-    # another vote in the two runs (above; up to 1e-2 of the largest entry each): an L2 perturbation of ~3e-4 of the
-    # cotangent, which is what these gradients then differ by (measured worst 9.0e-4, mlp_module.0.bias).
+    # Parameters BEHIND the max-pool (the proposal heads) hold 1e-4.  The max-pool routes a ball's gradient to the arg-max
+    # vote; ~1e-3 of the routes differ between two fp32 evaluations (above: `dvote_features_outliers`, up to 1e-2 of the
+    # largest entry each).  Two classes in front of it:
+    #  * the shared MLP of the vote aggregation sits directly under the routing: its gradients move with WHICH routes
+    #    differ (measured 9.0e-4 in exact mode, 3.5e-3 in split16 mode -- with FEWER differing routes, 7.3e-4 against
+    #    9.8e-4 of the entries: the mode changes which ties fall which way, not the size of the effect).  These tensors
+    #    are produced by the exact vote-aggregation kernels in BOTH modes: bound 5e-3;
+    #  * voting and the backbone -- where the split16 kernels live -- receive the routed gradient through d vote_features,
+    #    an L2 perturbation of ~3e-4 of the cotangent: bound 5e-4 (was 2e-3; measured 3.5e-4 exact, 1.8e-4 split16).
     behind = lambda n: n.startswith('detection.') and not n.startswith('detection.vote_aggregation.')   # noqa: E731
-    bad = {n: v for n, v in worst.items() if not v <= (tol if behind(n) else 2e-3)}
+    routed = lambda n: n.startswith('detection.vote_aggregation.')                                      # noqa: E731
+    bad = {n: v for n, v in worst.items() if not v <= (tol if behind(n) else (5e-3 if routed(n) else 5e-4))}
     assert not bad, bad
     assert max(v for n, v in worst.items() if behind(n)) <= tol
 
