@@ -196,53 +196,53 @@ class SplitPlanes(object):
         self.wh, self.winv = wh, winv
 
 
-def split_planes(W, pairs):
+def _pairs_index(pairs, K, transposed):
+    """source positions (see math_mode.pack_parts; M = K * 4096) of the plane-pair operand layout
+    out[pair][ph][part][m][16 kg + r][i] = part of W_{plane (i < 4 ? a : b)}[16 m + r][16 ph + kg + 4 (i & 3)]
+    (transposed: of W_k^T, i.e. element [row][col] comes from W_k[col][row])"""
+    import numpy as np
+    M = K * 4096
+    P = len(pairs)
+    pa = np.array(pairs, dtype=np.int64)                                   # (P, 2)
+    sh = (P, 4, 3, 4, 4, 16, 8)                                            # pair, ph, part, m, kg, r, i
+    pi, ph, part, m, kg, r, i = np.meshgrid(*[np.arange(n) for n in sh], indexing='ij')
+    plane = pa[pi, i >> 2]
+    row, col = 16 * m + r, 16 * ph + kg + 4 * (i & 3)
+    src = part * M + plane * 4096 + (col * 64 + row if transposed else row * 64 + col)
+    return np.where(plane >= 0, src, 3 * M).reshape(-1).astype(np.int64)
+
+
+def split_planes(W, pairs, transposed=False):
     """W [..., K][64 rows][64 cols] fp32 (leading batch dimensions allowed: one scale per leading index), pairs = the
     schedule's plane pairs -> (wh [..., P, 4, 3 parts, 4, 64, 8] fp16, winv [..., 1] fp32):
-    wh[pair][ph][part][m][16 kg + r][i] = part of 2^S W_{plane (i < 4 ? a : b)}[16 m + r][16 ph + kg + 4 (i & 3)]."""
-    lead = W.shape[:-3]
-    n = len(lead)
-    s, inv = math_mode.weight_scale(W, dims=(-3, -2, -1))
-    Ws = W.detach() * s
-    zero = torch.zeros_like(Ws[..., 0, :, :])
-    sel = torch.stack([torch.stack([Ws[..., a, :, :], Ws[..., b, :, :] if b >= 0 else zero], dim=n) for a, b in pairs],
-                      dim=n)                                                  # (..., P, 2, 64, 64)
-    parts = math_mode.split_parts(sel)
-    P = len(pairs)
-
-    def order(a):       # (..., P, h, m, r, ph, q, kg) -> (..., P, ph, m, kg, r, h, q)
-        a = a.reshape(*lead, P, 2, 4, 16, 4, 4, 4)
-        return a.permute(*range(n), n, n + 4, n + 2, n + 6, n + 3, n + 1, n + 5).reshape(*lead, P, 4, 4, 64, 8)
-    return torch.stack([order(a) for a in parts], dim=n + 2).contiguous(), inv.reshape(*lead, 1).contiguous()
+    wh[pair][ph][part][m][16 kg + r][i] = part of 2^S W_{plane (i < 4 ? a : b)}[16 m + r][16 ph + kg + 4 (i & 3)]
+    (transposed=True: of W_k^T -- the data gradient's planes -- without materialising the transposed tensor)."""
+    K = W.shape[-3]
+    flat, inv = math_mode.pack_parts(W, W.dim() - 3)
+    wh = math_mode.gather_layout(flat, ('gcn_pairs', tuple(pairs), K, bool(transposed)),
+                                 lambda: _pairs_index(pairs, K, transposed))
+    return wh.view(*W.shape[:-3], len(pairs), 4, 3, 4, 64, 8), inv
 
 
-def split_unit_counts(tables):
-    """(forward, data gradient): (plane pair, joint) units of the split16 schedules per 16-frame tile and channel phase --
-    a unit is live when either plane of the pair has a non-empty neighbour list at the joint (12 MFMAs each)."""
+def _coef_grad_index(K):
+    """source positions of out[k][ph][part (w1, w2)][ks][16 kg + r][i] = W_k[16 ph + r][32 ks + 16 (i >> 2) + 4 (i & 3) + kg]"""
     import numpy as np
-    out = []
-    for gidx, Lk, pairs in ((tables.gidx_c, tables.Lk_c, tables.pairs_c), (tables.gidx_r, tables.Lk_r, tables.pairs_r)):
-        g = gidx.numpy()
-        lofs = np.concatenate([[0], np.cumsum(Lk)])
-        live = np.stack([(g[lofs[k]:lofs[k + 1]] >= 0).any(0) for k in range(tables.K)])
-        out.append(int(sum((live[a] | (live[b] if b >= 0 else False)).sum() for a, b in pairs)))
-    return tuple(out)
+    M = K * 4096
+    sh = (K, 4, 2, 2, 4, 16, 8)                                            # k, ph, part, ks, kg, r, i
+    k, ph, part, ks, kg, r, i = np.meshgrid(*[np.arange(n) for n in sh], indexing='ij')
+    row, col = 16 * ph + r, 32 * ks + 16 * (i >> 2) + 4 * (i & 3) + kg
+    return (part * M + k * 4096 + row * 64 + col).reshape(-1).astype(np.int64)
 
 
-def split_planes_coef_grad(W):
+def split_planes_coef_grad(W, packed=None):
     """W [..., K][64 rows][64 cols] fp32 (forward planes; one scale per leading index) -> the A operands of the split16
     adjacency-gradient kernel (csrc/stgcn_gcn3h_grad.hip): (wd [..., K, 4 ph, 2 parts, 2 ks, 64, 8] fp16, winv [..., 1]):
-    wd[k][ph][part][ks][16 kg + r][i] = part of 2^S W_k[16 ph + r][32 ks + 16 (i >> 2) + 4 (i & 3) + kg]."""
-    lead = W.shape[:-3]
-    n = len(lead)
+    wd[k][ph][part][ks][16 kg + r][i] = part of 2^S W_k[16 ph + r][32 ks + 16 (i >> 2) + 4 (i & 3) + kg].
+    packed: (flat, inv) of math_mode.pack_parts(W, ...) when the caller already has it."""
     K = W.shape[-3]
-    s, inv = math_mode.weight_scale(W, dims=(-3, -2, -1))
-    p, q, _ = math_mode.split_parts(W.detach() * s)
-
-    def order(a):       # (..., K, ph, r, ks, h, q, kg) -> (..., K, ph, ks, kg, r, h, q)
-        a = a.reshape(*lead, K, 4, 16, 2, 2, 4, 4)
-        return a.permute(*range(n), n, n + 1, n + 3, n + 6, n + 2, n + 4, n + 5).reshape(*lead, K, 4, 2, 64, 8)
-    return torch.stack([order(p), order(q)], dim=n + 2).contiguous(), inv.reshape(*lead, 1).contiguous()
+    flat, inv = packed if packed is not None else math_mode.pack_parts(W, W.dim() - 3)
+    wd = math_mode.gather_layout(flat, ('gcn_coef_grad', K), lambda: _coef_grad_index(K))
+    return wd.view(*W.shape[:-3], K, 4, 2, 2, 64, 8), inv
 
 
 def split_weight_grad_units(tables):
@@ -296,7 +296,7 @@ class _GraphConv(Function):
         if split is None and math_mode.split16() and _gen3h_able(x, tables):
             W3 = W.view(tables.K, 64, 64)
             split = (SplitPlanes(*split_planes(W3, tables.pairs_c)),
-                     SplitPlanes(*split_planes(W3.transpose(1, 2), tables.pairs_r)),
+                     SplitPlanes(*split_planes(W3, tables.pairs_r, transposed=True)),
                      SplitPlanes(*split_planes_coef_grad(W3)))
         if split is not None and _gen3h_able(x, tables):
             # split16 mode: two-part fp16 products (csrc/stgcn_gcn3h_body.h); x's range word stays with the op -- x is an
@@ -572,12 +572,12 @@ def prepare_chain(blocks, A, importances, tables, frames=None):
         if split:
             from . import tconv_op
             math_mode.reset()
+            # one (scale, three fp16 planes) per weight tensor, then one gather per operand layout: a dozen launches
             gsf, gsf_inv = split_planes(W, tables.pairs_c)
-            gsb, gsb_inv = split_planes(W.transpose(-1, -2), tables.pairs_r)
+            gsb, gsb_inv = split_planes(W, tables.pairs_r, transposed=True)
             gsd, gsd_inv = split_planes_coef_grad(W)
-            W3 = Wt.permute(0, 3, 1, 2)                                          # (B, tap, c, ci)
-            tsf, tsf_inv = tconv_op.split_taps(W3)
-            tsb, tsb_inv = tconv_op.split_taps(W3.flip(1).transpose(-1, -2))    # data gradient: tap p' = W[2 - p']^T
+            tsf, tsf_inv = tconv_op.split_taps(Wt, layout='cit')                # Wt (B, c, ci, tap): the Conv2d weight itself
+            tsb, tsb_inv = tconv_op.split_taps(Wt, layout='cit', gradient=True)  # data gradient: tap p' = W[2 - p']^T
     out = []
     A_b, cc, cr, bc = Aeff.unbind(0), coef_c.unbind(0), coef_r.unbind(0), bias_cv.unbind(0)
     for i in range(B):

@@ -109,3 +109,30 @@ def split_parts(ws):
     q = (ws - pf).to(torch.float16)
     ps = (pf * 2.0 ** -11).to(torch.float16)
     return p, q, ps
+
+
+def pack_parts(W, n_lead):
+    """W fp32 [lead..., ...] -> (flat [lead..., 3 M + 1] fp16, inv [lead..., 1] fp32), M = elements per leading index:
+    the three fp16 planes (w1, w2, 2^-11 w1) of 2^S W one behind the other (in W's own element order) and one zero.  The
+    kernels' operand layouts are then ONE index_select each along the last axis (`gather_layout`): the whole per-step
+    weight preparation of a stack of blocks is a dozen launches, whatever the number of layouts."""
+    lead = W.shape[:n_lead]
+    s, inv = weight_scale(W, dims=tuple(range(n_lead, W.dim())))
+    p, q, ps = split_parts(W.detach() * s)
+    zero = torch.zeros(*lead, 1, dtype=torch.float16, device=W.device)
+    flat = torch.cat([p.reshape(*lead, -1), q.reshape(*lead, -1), ps.reshape(*lead, -1), zero], dim=-1)
+    return flat, inv.reshape(*lead, 1).contiguous()
+
+
+_INDEX = {}     # (layout key, device) -> int64 index tensor
+
+
+def gather_layout(flat, key, build):
+    """flat from `pack_parts`; `build()` -> numpy int64 array of source positions in [0, 3 M] (3 M = the zero) for the
+    operand layout `key`; cached per device."""
+    k = (key, str(flat.device))
+    idx = _INDEX.get(k)
+    if idx is None:
+        idx = _INDEX[k] = torch.from_numpy(build()).to(flat.device)
+    return flat.index_select(-1, idx)
+

@@ -43,19 +43,29 @@ class SplitTaps(object):
         self.wh, self.winv = wh, winv
 
 
-def split_taps(W3):
-    """W3 [..., 3 taps][64 co][64 ci] fp32 (leading batch dimensions allowed: one scale per leading index) ->
-    (wh [..., 3 parts, 3, 2, 4, 64, 8] fp16, winv [..., 1] fp32), parts = (w1, w2, 2^-11 w1) (math_mode.split_parts):
-    wh[part][tap][ks][w][16 kg + r][i] = part of 2^S W3[tap][16 w + r][32 ks + 8 kg + i]."""
-    lead = W3.shape[:-3]
-    s, inv = math_mode.weight_scale(W3, dims=(-3, -2, -1))
-    parts = math_mode.split_parts(W3.detach() * s)
-    n = len(lead)
+def _taps_index(layout, gradient):
+    """source positions (math_mode.pack_parts; M = 3 * 4096) of out[part][tap][ks][w][16 kg + r][i] = part of
+    A[tap][16 w + r][32 ks + 8 kg + i], A = W3 (forward) or the data gradient's taps A[p'] = W3[2 - p']^T;
+    layout 'tci': the source is W3 [tap][co][ci]; 'cit': the Conv2d weight [co][ci][tap]"""
+    import numpy as np
+    M = 3 * 4096
+    sh = (3, 3, 2, 4, 4, 16, 8)                                            # part, tap, ks, w, kg, r, i
+    part, tap, ks, w, kg, r, i = np.meshgrid(*[np.arange(n) for n in sh], indexing='ij')
+    arow, acol = 16 * w + r, 32 * ks + 8 * kg + i
+    t, co, ci = (2 - tap, acol, arow) if gradient else (tap, arow, acol)
+    pos = (t * 64 + co) * 64 + ci if layout == 'tci' else (co * 64 + ci) * 3 + t
+    return (part * M + pos).reshape(-1).astype(np.int64)
 
-    def order(a):       # (..., tap, w, r, ks, kg, i) -> (..., tap, ks, w, kg, r, i)
-        a = a.reshape(*lead, 3, 4, 16, 2, 4, 8)
-        return a.permute(*range(n), n, n + 3, n + 1, n + 4, n + 2, n + 5).reshape(*lead, 3, 2, 4, 64, 8)
-    return torch.stack([order(a) for a in parts], dim=n).contiguous(), inv.reshape(*lead, 1).contiguous()
+
+def split_taps(W, layout='tci', gradient=False):
+    """The (3,1) convolution's weights as operands of the split16 kernel.  W fp32 with leading batch dimensions allowed
+    (one scale per leading index): layout 'tci' = [..., 3 taps][64 co][64 ci], 'cit' = [..., 64 co][64 ci][3 taps] (the
+    Conv2d weight).  gradient: the data gradient's taps, tap p' = W[2 - p']^T.  ->
+    (wh [..., 3 parts, 3, 2, 4, 64, 8] fp16, winv [..., 1] fp32), parts = (w1, w2, 2^-11 w1) (math_mode.split_parts):
+    wh[part][tap][ks][w][16 kg + r][i] = part of 2^S A[tap][16 w + r][32 ks + 8 kg + i]."""
+    flat, inv = math_mode.pack_parts(W, W.dim() - 3)
+    wh = math_mode.gather_layout(flat, ('tconv_taps', layout, bool(gradient)), lambda: _taps_index(layout, gradient))
+    return wh.view(*W.shape[:-3], 3, 3, 2, 4, 64, 8), inv
 
 
 def _tconvh_able(taps, x):
@@ -159,7 +169,7 @@ class _BNReLUTConv(Function):
             W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]
             out = _tconvh(z, fin[2], fin[3], SplitTaps(*split_taps(W3)), bias.contiguous() if bias is not None else None,
                           want_stats)
-            wp_b = SplitTaps(*split_taps(W3.flip(0).transpose(1, 2)))                # data gradient: tap p' = W[2 - p']^T
+            wp_b = SplitTaps(*split_taps(W3, gradient=True))                         # data gradient: tap p' = W[2 - p']^T
             ctx.save_for_backward(z, fin)
         else:
             W3 = weight.reshape(64, 64, taps).permute(2, 0, 1).contiguous()         # [tap][c][ci]

@@ -12,7 +12,8 @@ REPS=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ
 REPS=1 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm2 -- python $R/$WORKLOAD > $R/gpurun_out/pm2.log 2>&1
 python - <<PY
 import csv, glob, json, collections
-KEYS = ('gcn3h_kernel', 'tconv_dw_f16_kernel', 'tconv_f16w_kernel', 'gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn3_dw_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel',
+KEYS = ('gcn3h_fwd_kernel', 'gcn3h_dx_kernel', 'gcn3dwh_kernel', 'gcn3h_dcoef_kernel', 'tconvh_kernel<true, false>', 'tconvh_kernel<false, true>', 'tconvh_kernel<false, false>',
+        'gcn3h_kernel', 'tconv_dw_f16_kernel', 'tconv_f16w_kernel', 'gcn3_kernel', 'gcn3_dcoef_kernel', 'gcn3_dw_kernel', 'gcn2_kernel', 'gcn_fused_kernel', 'gcn_dw_kernel', 'gcn_dcoef_kernel',
         'tconv3_kernel<true, false, 3,', 'tconv3_kernel<false, false, 3,', 'tconv3_kernel<true, false, 1,', 'tconv3_kernel<false, false, 1,',
         'tconv_dw_kernel<3', 'tconv_dw_kernel<1')
 def load(d):
