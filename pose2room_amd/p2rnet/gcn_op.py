@@ -245,6 +245,19 @@ def split_planes_coef_grad(W, packed=None):
     return wd.view(*W.shape[:-3], K, 4, 2, 2, 64, 8), inv
 
 
+def split_unit_counts(tables):
+    """(forward, data gradient): (plane pair, joint) units of the split16 schedules per 16-frame tile and channel phase --
+    a unit is live when either plane of the pair has a non-empty neighbour list at the joint (12 MFMAs each)."""
+    import numpy as np
+    out = []
+    for gidx, Lk, pairs in ((tables.gidx_c, tables.Lk_c, tables.pairs_c), (tables.gidx_r, tables.Lk_r, tables.pairs_r)):
+        g = gidx.numpy()
+        lofs = np.concatenate([[0], np.cumsum(Lk)])
+        live = np.stack([(g[lofs[k]:lofs[k + 1]] >= 0).any(0) for k in range(tables.K)])
+        out.append(int(sum((live[a] | (live[b] if b >= 0 else False)).sum() for a, b in pairs)))
+    return tuple(out)
+
+
 def split_weight_grad_units(tables):
     """live (plane, group of 8 joints) units of the split16 weight-gradient schedule per 4-frame tile (24 MFMAs per unit and
     wave, two waves -- the column halves -- per plane set)"""

@@ -113,3 +113,18 @@ def test_split_schedules_match_their_generator():
         for f in forms:
             path, text = (mod.path(f), mod.generate(f)) if f else (mod.path(), mod.generate())
             assert open(path).read() == text, path
+
+
+def test_split_schedule_unit_counts():
+    """the FLOP model of bench.py's split16 roofline counts the units the generated schedules contain"""
+    import re, os
+    from pose2room_amd.p2rnet import gcn_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    tables = gcn_op.GraphTables(Graph().A)
+    if not tables.gen3h:
+        pytest.skip('library not built for this skeleton')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def units(name, macro):
+        return int(re.search(r'#define %s (\d+)' % macro, open(os.path.join(root, 'pose2room_amd', 'csrc', name)).read()).group(1))
+    assert gcn_op.split_unit_counts(tables) == (units('gcn3h_sched_c.inc', 'H3_UNITS'), units('gcn3h_sched_r.inc', 'H3_UNITS'))
+    assert gcn_op.split_weight_grad_units(tables) == units('gcn3dwh_sched.inc', 'DW_UNITS')
