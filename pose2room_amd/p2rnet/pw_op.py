@@ -18,6 +18,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from . import bn_op
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -491,9 +492,13 @@ class _VoteHead(Function):
             _gemm([dict(x=_at(x), x_nlc=1, x_ctot=256, w=_at(W0), out=_at(Z1), out_ctot=256, stats=_at(s1), k=256,
                         rows=256)], B, S, st)
             _bn_finalize([seq[0].batchnorm], [s1], fin1, [0], st)
+            if bn_op.GATE_HOOK is not None:      # (the next layer evaluates relu(Z1 * scale + shift) on load)
+                bn_op.GATE_HOOK(seq[0].batchnorm, Z1, fin1[2], fin1[3], None)
             _gemm([dict(x=_at(Z1), x_ctot=256, tr=_at(fin1, 512), tr_mode=1, tr_ld=256, w=_at(W1), out=_at(Z2),
                         out_ctot=256, stats=_at(s2), k=256, rows=256)], B, S, st)
             _bn_finalize([seq[1].batchnorm], [s2], fin2, [0], st)
+            if bn_op.GATE_HOOK is not None:
+                bn_op.GATE_HOOK(seq[1].batchnorm, Z2, fin2[2], fin2[3], None)
             _gemm([dict(x=_at(Z2), x_ctot=256, tr=_at(fin2, 512), tr_mode=1, tr_ld=256, w=_at(W2), bias=_at(seq[2].conv.bias),
                         out=_at(net), out_ctot=R, out_nlc=1, k=256, rows=R)], B, S, st)
         ctx.module, ctx.train, ctx.dims = module, train, (B, S, R)

@@ -229,11 +229,13 @@ def _check_forward_and_loss(z, tag, ep, loss, tol, tol_loss):
     for b in np.nonzero(~same)[0]:
         assert fps_gap[b] < GAP_NOISE, f'sample {b}: proposal set differs although the FPS margin is {fps_gap[b]:.2e}'
     m['samples_with_other_proposals'] = int((~same).sum())
-    assert same.mean() >= 0.75
+    # measured on MI355X at these seeds, both arithmetic modes: every sample picks the reference's proposals (1.00); a
+    # sample may differ only through an FPS decision inside the noise band (asserted above), and only a few may
+    assert same.mean() >= 0.95, same.mean()
     solid = _ball_gaps(z[f'{tag}_vote_xyz'], ref_inds) >= GAP_NOISE          # (B, 128)
     solid &= same[:, None]
     m['solid_proposals'] = float(solid.mean())
-    assert solid.mean() >= 0.5
+    assert solid.mean() >= 0.98, solid.mean()          # measured 0.993 .. 0.996
     for k in ('aggregated_vote_xyz', 'center', 'size', 'heading', 'objectness_scores', 'sem_cls_scores'):
         got = ep[k].cpu().numpy(); ref = z[f'{tag}_{k}']
         assert got.dtype == ref.dtype, (k, got.dtype)
@@ -247,8 +249,10 @@ def _check_forward_and_loss(z, tag, ep, loss, tol, tol_loss):
         assert str(v.dtype) == str(z[f'{tag}_lossdtype_{k}']), (k, v.dtype)
         a, b = float(v), float(z[f'{tag}_loss_{k}'])
         m['loss_' + k] = abs(a - b) / max(1.0, abs(b))
-        if same.all():
-            assert m['loss_' + k] <= tol_loss, (k, a, b)
+        # the losses are batch means: with every sample on the reference's proposals they hold tol_loss; a sample on
+        # another proposal set (FPS decision inside the noise band) moves them by at most its share of the batch
+        slack = tol_loss if same.all() else tol_loss + float((~same).mean())
+        assert m['loss_' + k] <= slack, (k, a, b, int((~same).sum()))
     return m
 
 
@@ -289,27 +293,37 @@ def test_g10c_backbone_backward_vs_reference(dev, mathmode):
       * train-mode BatchNorm backward cancels most of its input (mean and projection removed): the fixture says how far
         the reference's OWN float32 run is from its float64 run, per tensor (1e-3 .. 4e-3 of the largest entry through the
         six blocks) -- our error may be FACTOR times that;
-      * a ReLU bit: the forward agrees to 3e-6, so of the 4096 x 256 pre-activations of a vote-head layer about one sits
-        inside the noise and takes the other branch.  One such element moves a BatchNorm-bias gradient (a sum of 4096
-        terms of either sign, largest entry ~ 64 terms) by 1/64 of its scale and perturbs everything upstream by a
-        rank-one term (measured on MI355X: 5.2e-3 on centervoting.conv_input.1.batchnorm.bias, 5e-4 on conv_joint.weight,
-        where the reference's two runs happen to agree to 1e-6; the vote head alone, fed identical activations, holds 1e-6
-        against fp64: tools/dev_votehead_precision.py).  Hence the second bound, FLIP of the largest entry, for
-        every tensor upstream of a ReLU; the last voting layer (behind every ReLU) must hold 2e-4.
+      * a ReLU bit: the forward agrees to 3e-6, so of the 4096 x 256 pre-activations of a vote-head layer (and of the 28 M
+        of an ST-GCN gate) a few sit inside the noise and take the other branch.  One such element moves a BatchNorm-bias
+        gradient by up to 1/64 of its scale and perturbs everything upstream by a rank-one term (round 5 measured 5.2e-3
+        on centervoting.conv_input.1.batchnorm.bias and covered it with a blanket bound of 1e-2 on ~78 tensors).  The
+        fixture now carries the reference's near-zero pre-activations of all fourteen gate layers (`g10c_gate_*`,
+        make_headline_golden.py g): GateForcer finds the gates that are in another state here, asserts each lies inside
+        the recorded band, and pins it to the reference's state BEFORE the fused kernels evaluate it -- the backward then
+        runs with the reference's gates and every tensor is held at FACTOR times the reference's own float32 error
+        (floor: the north star's 1e-4 of the tensor's largest entry).
     As a whole our fp32 run must be as close to float64 as the reference's fp32 run: median over the tensors <= 2x.
     Gradients that vanish analytically (a conv bias in front of a train-mode BatchNorm) are compared on the scale of
     the largest gradient in the net."""
     from tests import cases
     from pose2room_amd.p2rnet.synthetic import make_batch
-    FACTOR, FLIP = 4.0, 1e-2
+    from tests.test_model_cpu import GateForcer
+    FACTOR, FLOOR_REL = 4.0, 1e-4
     z = np.load(G10)
     B, T = 8, 1024
     net, cfg = _ref_net(T, dev)
     net.train(); net.zero_grad()
     batch = make_batch(B, T, seed=2024, device=dev)
-    xyz, feats, ep = net._votes(batch)
-    gx, gf = cases.seam_cotangents(B)
-    torch.autograd.backward([xyz, feats], [gx.to(dev), gf.to(dev)])
+    with GateForcer(net, z, 'g10c') as gates:
+        xyz, feats, ep = net._votes(batch)
+        gx, gf = cases.seam_cotangents(B)
+        torch.autograd.backward([xyz, feats], [gx.to(dev), gf.to(dev)])
+    # fourteen gate layers were looked at; the pinned gates are few and all inside the reference's near-zero band
+    # (GateForcer asserts the band); the count is bounded so that a real disagreement cannot hide behind the pinning
+    ncand = sum(int(z[k].size) for k in z.files if k.startswith('g10c_gate_') and k.endswith('_idx'))
+    print(f'g10c gates: {len(gates.forced)} of {ncand} near-zero candidates pinned:', gates.forced[:12])
+    assert gates.layers == 14 and len(gates.seen) == 14, gates.seen
+    assert len(gates.forced) <= max(8, ncand // 100), (len(gates.forced), ncand)
     assert np.array_equal(ep['seed_inds'].cpu().numpy(), z['g10c_seed_inds'])
     fwd = {'vote_xyz': _relmax(xyz.detach().cpu().numpy(), z['g10c_vote_xyz']),
            'vote_features': float(np.abs(feats.detach()[:, ::16, ::8].cpu().numpy() - z['g10c_vote_features_sub']).max()
@@ -324,7 +338,7 @@ def test_g10c_backbone_backward_vs_reference(dev, mathmode):
         err, scale = _packed_err(z, f'g10c_grad_{n}', params[n].grad)
         ref32 = float(z[f'g10c_grad_{n}_ref32']) * scale               # the reference's own fp32 error, absolute
         behind_every_relu = n.startswith('centervoting.conv_input.2.')
-        bound = max(FACTOR * ref32, (2e-4 if behind_every_relu else FLIP) * max(scale, floor))
+        bound = max(FACTOR * ref32, (2e-4 if behind_every_relu else FLOOR_REL) * max(scale, floor))
         rows.append((err.max() / max(scale, floor), ref32 / max(scale, floor), n))
         if not err.max() <= bound:
             bad[n] = f'err {err.max():.3e} > bound {bound:.3e} (reference fp32 {ref32:.3e}, largest entry {scale:.3e})'

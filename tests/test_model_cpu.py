@@ -165,11 +165,15 @@ class GateForcer(object):
         self.forced = []
         self.seen = set()
         self.by_bn = {}
-        for i, blk in enumerate(net.backbone.st_gcn_networks):
-            for kind, bn in (('t', blk.tcn[0]), ('o', blk.tcn[3])):
-                key = f'{tag}_gate_{kind}{i}'
-                self.by_bn[id(bn)] = (key, torch.from_numpy(z[key + '_idx']), torch.from_numpy(z[key + '_val']),
-                                      float(z[key + '_lim']))
+        layers = [(f't{i}', blk.tcn[0]) for i, blk in enumerate(net.backbone.st_gcn_networks)]
+        layers += [(f'o{i}', blk.tcn[3]) for i, blk in enumerate(net.backbone.st_gcn_networks)]
+        # the two ReLUs of the vote head (fixtures that carry them)
+        layers += [(f'v{i}', net.centervoting.conv_input[i].batchnorm) for i in (0, 1) if f'{tag}_gate_v{i}_idx' in z.files]
+        for name, bn in layers:
+            key = f'{tag}_gate_{name}'
+            self.by_bn[id(bn)] = (key, torch.from_numpy(z[key + '_idx']), torch.from_numpy(z[key + '_val']),
+                                  float(z[key + '_lim']))
+        self.layers = len(layers)
 
     def __call__(self, bn, x, scale, shift, res):
         ent = self.by_bn.get(id(bn))
