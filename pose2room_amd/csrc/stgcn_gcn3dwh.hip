@@ -9,7 +9,7 @@
 // 56 live of 77 instead of 369 (plane, joint) units of one fp32 k-step each.  Both operands are runtime tensors:
 //   * X (an activation) is split ONCE per tile by the whole workgroup on its way into LDS (register-staged, fp16 operand
 //     slots [row][frame][part][56 joints]) and serves every wave and plane;
-//   * the aggregate V_k is built in fp32 from the dZ tile (LDS-DMA, as the tensor has it), with the coefficients as a
+//   * the aggregate V_k is built in fp32 from the dZ tile (register-staged into a bank-friendly layout), with the coefficients as a
 //     contiguous stream in schedule order that carries the power of two of dZ's range word, and split per unit; dZ is a
 //     gradient -- heavy-tailed -- so its residual part is kept scaled by 2^11 and meets 2^-11 x1 (split16.h), formed
 //     from x1 when a group's operands are read;
@@ -25,41 +25,35 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int V = 53, F = 4, NW = 8, C = 64;
-constexpr int RL = F * V;                 // 212 floats per tile row
-constexpr int TILE = C * RL;
-constexpr int NV4 = TILE / 4;             // 3392 float4 = 53 pieces of 64
-constexpr int PIECES = (NV4 + 63) / 64;
-constexpr int PW = (PIECES + NW - 1) / NW;
 constexpr int set_planes[4][DW_MAXPL] = DW_SET_PLANES;
 constexpr int cs_off[4] = DW_CS_OFF;
 __device__ const int dw_cs_idx[DW_NCS] = DW_CS_IDX;      // the coefficient stream: indices into the flattened [ltot][53] table
-// X in LDS: already split, [row][frame][part][56 joints] halves (joints 53-55 zero): what lane (kg, r) reads for a group is
-// one 16-byte slot per part.  Built once per tile by the whole workgroup (eight waves would otherwise split the same group)
-constexpr int XJ = 56, XROW = F * 2 * XJ;            // 448 halves = 896 bytes per row
-constexpr int XTILE_F = C * XROW / 2;                // the split tile in floats (57,344 bytes)
+// Both tiles are staged through registers into layouts chosen for the LDS banks (profiles/r6_split16_mfma_util.json: with
+// the dZ tile as LDS-DMA leaves it -- rows of 212 floats -- and X slots of 224 bytes, 49 % of the kernel's LDS cycles were
+// bank conflicts):
+//  * dZ [row c][frame][joint]: row stride DZR = 321 floats (1 mod 32), frame stride DZF = 80 (16 mod 32).  A gather reads,
+//    per 32-lane half of the wave, rows r = 0..15 at frames kg and kg + 1 of one joint: banks r + 16 kg (+ joint): all 32
+//    different;
+//  * X, already split: [frame][row] slots of XSLOT = 240 bytes = [part][56 joints] halves + 16 bytes of padding.  A
+//    16-byte operand read serves 8 lanes per cycle -- rows r .. r + 7 of one frame: 60 r mod 32 words = eight different
+//    4-bank groups.
+constexpr int DZR = 321, DZF = 80;
+constexpr int DZ_TILE = C * DZR;                     // floats (82,176 bytes)
+constexpr int XJ = 56, XSLOT = 240;                  // joints per part (53 + 3 zeros), bytes per (frame, row) slot
+constexpr int XTILE_F = F * C * XSLOT / 4;           // the split tile in floats (61,440 bytes)
 constexpr int BITEMS = (C * V + NW * 64 - 1) / (NW * 64);      // (channel, joint) sums of the bias-table gradient per thread: 7
 
 struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
 struct Params { int T, tiles_per_seq, total_tiles; const unsigned *x_amax, *dz_amax; };
 struct Split { p2r_h8 p, q; };
 
-__device__ __forceinline__ unsigned lds_addr(const float *p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
-}
-__device__ __forceinline__ void dma16(const float *base, unsigned voff, float *lds_dst) {
-  unsigned keep;
-  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_dst));
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
-}
-
 // a group's X operands: the two parts of rows 16 m + r, frame kg, joints 8 grp .. 8 grp + 7, and 2^-11 x1 for the product
 // with the aggregate's scaled residual
 #define DW_A(grp)                                                                                \
   {                                                                                              \
     _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                           \
-      A[m_].p = *reinterpret_cast<const p2r_h8 *>(xl + m_ * (16 * XROW * 2) + 16 * (grp));       \
-      A[m_].q = *reinterpret_cast<const p2r_h8 *>(xl + m_ * (16 * XROW * 2) + XJ * 2 + 16 * (grp)); \
+      A[m_].p = *reinterpret_cast<const p2r_h8 *>(xl + m_ * (16 * XSLOT) + 16 * (grp));          \
+      A[m_].q = *reinterpret_cast<const p2r_h8 *>(xl + m_ * (16 * XSLOT) + XJ * 2 + 16 * (grp)); \
       As[m_] = A[m_].p * (_Float16)(1.0 / P2R_RES_SCALE);                                        \
     }                                                                                            \
   }
@@ -67,7 +61,7 @@ __device__ __forceinline__ void dma16(const float *base, unsigned voff, float *l
 #define DW_G(i, first, off, e)                                                                   \
   {                                                                                              \
     const float c_ = *reinterpret_cast<const float *>(cl + 4 * (e));                             \
-    const float d0_ = *reinterpret_cast<const float *>(dl + (off)), d1_ = *reinterpret_cast<const float *>(dl + 16 * RL * 4 + (off)); \
+    const float d0_ = *reinterpret_cast<const float *>(dl + (off)), d1_ = *reinterpret_cast<const float *>(dl + 16 * DZR * 4 + (off)); \
     Vg[i] = (first) ? c_ * d0_ : fmaf(c_, d0_, Vg[i]);                                           \
     Vh[i] = (first) ? c_ * d1_ : fmaf(c_, d1_, Vh[i]);                                           \
   }
@@ -88,33 +82,27 @@ __device__ __forceinline__ void dma16(const float *base, unsigned voff, float *l
 template <int SET>
 __device__ __forceinline__ void wave_main(const Params &p, float *lds, const float *__restrict__ x, const float *__restrict__ dz,
                                           float *__restrict__ part, float *__restrict__ bpart, float xs, float inv) {
-  float *xt = lds, *dt = lds + XTILE_F, *coef_l = dt + TILE;
+  float *xt = lds, *dt = lds + XTILE_F, *coef_l = dt + DZ_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kg = lane >> 4, r = lane & 15, half = wave & 1;
   const size_t row_stride = (size_t)p.T * V;
   // A operand: X[16 m + r][frame kg][joint 8 grp + i]; gathers: dZ[16 (2 half + n) + r][frame kg][w]
-  const char *xl = reinterpret_cast<const char *>(xt) + (r * F + kg) * (2 * XJ * 2);
-  const char *dl = reinterpret_cast<const char *>(dt + (32 * half + r) * RL + kg * V);
+  const char *xl = reinterpret_cast<const char *>(xt) + (kg * C + r) * XSLOT;
+  const char *dl = reinterpret_cast<const char *>(dt + (32 * half + r) * DZR + kg * DZF);
   unsigned cl_off = (unsigned)((coef_l - lds + cs_off[SET]) * sizeof(float));
   asm volatile("" : "+v"(cl_off));                     // opaque base: the coefficient reads stay LDS reads (stgcn_gcn3.hip)
   const char *cl = reinterpret_cast<const char *>(lds) + cl_off;
 
-  int doff[PW];
-#pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    const int pc = i * NW + wave, e = pc * 64 + lane;
-    const int row = e / (RL / 4), c4 = e - row * (RL / 4);
-    doff[i] = (pc < PIECES && e < NV4) ? (int)(((size_t)row * row_stride + 4 * c4) * sizeof(float)) : -1;
-  }
-
-  // this thread's items of the X tile: global offset (floats) and LDS offset (halves) of (row, frame, 4-joint chunk)
-  int xg[7], xo[7];
+  // this thread's items of the two tiles, (row, frame, 4-joint chunk): global offset (floats, the same for X and dZ) and
+  // the LDS offsets (X: halves; dZ: floats)
+  int xg[7], xo[7], zo[7];
   bool xlast[7];                                       // the chunk that holds joint 52 alone (53 = 13 x 4 + 1)
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int item = i * NW * 64 + tid, row = item / (F * (XJ / 4)), rem = item % (F * (XJ / 4)), f = rem / (XJ / 4), ch = rem % (XJ / 4);
     xg[i] = (int)((size_t)row * row_stride + f * V + 4 * ch);
-    xo[i] = (row * F + f) * (2 * XJ) + 4 * ch;
+    xo[i] = (f * C + row) * (XSLOT / 2) + 4 * ch;
+    zo[i] = row * DZR + f * DZF + 4 * ch;
     xlast[i] = 4 * ch + 4 > V;
   }
   f32x4 acc[DW_MAXPL][2][4];
@@ -131,24 +119,31 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   p2r_h8 As[4];
   float Vg[8], Vh[8];
 
-  // The X tile goes through registers (it is scaled and converted on the way); the dZ tile is copied by LDS-DMA.  Neither
-  // has a second home in LDS: both are fetched between the tiles (a prefetch of X under the units costs 28 live registers
-  // and spills: measured slower in the round-5 prototype).
-  float xv[7][4];
+  // Both tiles go through registers: X is scaled and converted on the way, dZ lands in its bank-friendly layout.  Neither
+  // has a second home in LDS: both are fetched between the tiles, all fourteen loads of a thread in flight together.
+  float xv[7][4], zv[7][4];
   auto tile_base = [&](int tile) {
     const int seq = tile / p.tiles_per_seq, t0 = (tile % p.tiles_per_seq) * F;
     return (size_t)seq * C * row_stride + (size_t)t0 * V;
   };
-  auto fetch_x = [&](size_t base) {
+  auto fetch = [&](const float *t, size_t base, float (&v)[7][4]) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const float *src = x + base + xg[i];
+      const float *src = t + base + xg[i];
       if (!xlast[i]) {       // one 16-byte load at 4-byte alignment
-        const F4 v = *reinterpret_cast<const F4 *>(src);
-        xv[i][0] = v.x; xv[i][1] = v.y; xv[i][2] = v.z; xv[i][3] = v.w;
+        const F4 u = *reinterpret_cast<const F4 *>(src);
+        v[i][0] = u.x; v[i][1] = u.y; v[i][2] = u.z; v[i][3] = u.w;
       } else {               // joint 52 alone: nothing is read past the row's 53rd joint (the tensor may end there)
-        xv[i][0] = src[0]; xv[i][1] = 0.f; xv[i][2] = 0.f; xv[i][3] = 0.f;
+        v[i][0] = src[0]; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f;
       }
+    }
+  };
+  auto put_dz = [&]() {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      float *d = dt + zo[i];
+      d[0] = zv[i][0];
+      if (!xlast[i]) { d[1] = zv[i][1]; d[2] = zv[i][2]; d[3] = zv[i][3]; }
     }
   };
   auto put_x = [&]() {
@@ -167,12 +162,10 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   };
   for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
     const size_t base = tile_base(tile);
-#pragma unroll
-    for (int i = 0; i < PW; ++i)
-      if (doff[i] >= 0) dma16(dz + base, doff[i], dt + (i * NW + wave) * 256);
-    fetch_x(base);
+    fetch(x, base, xv);
+    fetch(dz, base, zv);
     put_x();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    put_dz();
     __syncthreads();
     if (bpart) {      // bias-table gradient: column sums of the dZ tile over its frames (fp32, as the tensor has it)
 #pragma unroll
@@ -180,8 +173,8 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
         const int item = i * NW * 64 + tid;
         if (item < C * V) {
           const int c = item / V, v = item - c * V;
-          const float *d = dt + c * RL + v;
-          bacc[i] += (d[0] + d[V]) + (d[2 * V] + d[3 * V]);
+          const float *d = dt + c * DZR + v;
+          bacc[i] += (d[0] + d[DZF]) + (d[2 * DZF] + d[3 * DZF]);
         }
       }
     }
@@ -215,7 +208,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gcn3dwh_kernel(Params p, const flo
                                                              const float *__restrict__ coef, float *__restrict__ part,
                                                              float *__restrict__ bpart) {
   extern __shared__ float lds[];
-  float *coef_l = lds + XTILE_F + TILE;
+  float *coef_l = lds + XTILE_F + DZ_TILE;
   const int tid = threadIdx.x;
   // operand scales from the range words: x (activation) is scaled when it is split, dZ through the coefficient stream;
   // the accumulators hold 2^(S_x + S_dz) dW
@@ -248,7 +241,7 @@ extern "C" int p2r_stgcn_gcn3h_weight_grad(int N, int T, int V_, int K, int ltot
   if (tiles > 0x7fffffffLL) return P2R_EINVAL;
   Params p;
   p.T = T; p.tiles_per_seq = T / F; p.total_tiles = (int)tiles; p.x_amax = x_amax; p.dz_amax = dz_amax;
-  const size_t lds = ((size_t)XTILE_F + TILE + (size_t)DW_NCS) * sizeof(float);
+  const size_t lds = ((size_t)XTILE_F + DZ_TILE + (size_t)DW_NCS) * sizeof(float);
   static unsigned char lds_ok[P2R_MAX_DEVICES];
   hipError_t e = p2r_allow_big_lds(gcn3dwh_kernel, lds_ok);
   if (e != hipSuccess) return (int)e;
