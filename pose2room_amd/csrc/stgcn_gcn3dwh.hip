@@ -160,7 +160,14 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
       *reinterpret_cast<h4 *>(xsl + xo[i] + XJ) = h4{qa.x, qa.y, qb.x, qb.y};
     }
   };
-  for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+  // Tile order as in stgcn_gcn3_dw.hip: a tile row is 848 bytes of a channel row -- 6.6 cache lines, neighbouring tiles
+  // share a line at each end -- and workgroup b runs on XCD b % 8: the 32 workgroups of an XCD walk 32 CONSECUTIVE tiles
+  // per round, so the shared lines are hits in that XCD's L2 (measured here before the change: 1.36x the algorithmic reads)
+  const int per_xcd = (gridDim.x & 7) == 0 ? (int)(gridDim.x >> 3) : 0;
+  const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  auto tile_of = [&](int i) { return per_xcd ? (i * 8 + xcd) * per_xcd + xslot : (int)(blockIdx.x + i * gridDim.x); };
+  int it = 0;
+  for (int tile = tile_of(0); tile < p.total_tiles; tile = tile_of(++it)) {
     const size_t base = tile_base(tile);
     fetch(x, base, xv);
     fetch(dz, base, zv);

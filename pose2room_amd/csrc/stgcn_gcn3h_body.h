@@ -294,7 +294,9 @@ __device__ __forceinline__ void h3_wave_main(const H3Params &p, float *lds, cons
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+#ifndef H3_ADDEND_LATE
         if (H3_HAS_ADDEND && p.addend) fetch_addend(m);       // in flight under the round's staging writes and barrier
+#endif
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i)
           if (sj[i] >= 0) {
@@ -305,6 +307,9 @@ __device__ __forceinline__ void h3_wave_main(const H3Params &p, float *lds, cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float4 *zrow = reinterpret_cast<float4 *>(z + toff + (size_t)16 * m * row_stride);
+#ifdef H3_ADDEND_LATE
+        if (H3_HAS_ADDEND && p.addend) fetch_addend(m);
+#endif
 #pragma unroll
         for (int it = 0; it < ITS; ++it)
           if (32 * it + 31 < R4 || 32 * it + scol < R4) {

@@ -17,8 +17,19 @@ b = (torch.randn(K * 64, device=dev) * 0.1).requires_grad_(True)
 imp = (1 + 0.1 * torch.randn(K, V, V, device=dev)).requires_grad_(True)
 At = torch.tensor(A, dtype=torch.float32, device=dev)
 go = torch.randn(N, 64, T, V, device=dev)
+from pose2room_amd.p2rnet import math_mode          # P2R_MATH=split16 (environment): the split16 graph-conv kernels
 for _ in range(3):
     z, part = gcn_op.graph_conv(x, w, b, At * imp, tables, want_stats=True)
     z.backward(go)
     bn_op._stats_partial(go)
+if math_mode.split16():      # the temporal conv's two split launches on the same tensors
+    from pose2room_amd.p2rnet import tconv_op
+    W3 = (torch.randn(3, 64, 64, device=dev) / 8)
+    st = tconv_op.SplitTaps(*tconv_op.split_taps(W3))
+    sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev)
+    fin = torch.stack([torch.zeros(64, device=dev), torch.ones(64, device=dev), sc, sh]).contiguous()
+    xd = x.detach()
+    for _ in range(3):
+        tconv_op._tconvh(xd, sc, sh, st, None, True)
+        tconv_op._tconvh(go, None, None, st, None, True, bwd=(xd, fin), x_word=math_mode.range_word(go))
 torch.cuda.synchronize()
