@@ -381,3 +381,67 @@ def test_graph_conv_split16_weight_gradient_heavy_tailed(dev, N, T):
     for i, (what, r) in enumerate((('dW', ref), ('dbias table', refb))):
         es, ee = _rel(out['split16'][i], r), _rel(out['exact'][i], r)
         assert es <= 1.5 * ee + FLOOR, (what, es, ee)
+
+
+@pytest.mark.parametrize("N,T", [(2, 40), (1, 7), (3, 130)])
+def test_split16_mode_falls_back_to_the_exact_kernels(dev, N, T):
+    """shapes the split kernels do not take (sequence lengths that are not whole 16-frame tiles) run the exact kernels in
+    split16 mode: no split entry point is called (they are replaced by a tripwire for the duration), and the results equal
+    the exact mode's up to the order-of-arrival noise of the first-generation kernels' LDS atomics"""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op, math_mode, tconv_op
+    A, x, w, b, imp, go = _gcn_case(N, T, 31)
+    tables = gcn_op.GraphTables(A)
+    At = torch.tensor(A, dtype=torch.float32)
+    bn = torch.nn.BatchNorm2d(64).to(dev).train()
+    conv = torch.nn.Conv2d(64, 64, (3, 1), (1, 1), (1, 0)).to(dev)
+    lib = _lib.lib()
+    names = ('p2r_stgcn_gcn3h_forward', 'p2r_stgcn_gcn3h_data_gradient', 'p2r_stgcn_gcn3h_weight_grad',
+             'p2r_stgcn_gcn3h_coef_grad', 'p2r_stgcn_tconvh_forward')
+    orig = {n: getattr(lib, n) for n in names}
+
+    def tripwire(*a):
+        raise AssertionError('a split16 kernel was launched on a shape it does not take')
+    res = {}
+    try:
+        for m in ('exact', 'split16'):
+            if m == 'split16':
+                for n in names:
+                    setattr(lib, n, tripwire)
+            xd, wd, bd, idv = (t.to(dev).requires_grad_(True) for t in (x, w, b, imp))
+            bn_m, conv_m = copy.deepcopy(bn), copy.deepcopy(conv)
+            with math_mode.use(m):
+                z = gcn_op.graph_conv(xd, wd, bd, At.to(dev) * idv, tables)
+                u = tconv_op.bn_relu_tconv(z, bn_m, conv_m)
+                u.backward(go.to(dev))
+            res[m] = (z.detach(), u.detach(), xd.grad, wd.grad, bd.grad, idv.grad, conv_m.weight.grad, bn_m.weight.grad)
+    finally:
+        for n in names:
+            setattr(lib, n, orig[n])
+    assert torch.equal(res['exact'][0], res['split16'][0]) and torch.equal(res['exact'][1], res['split16'][1])   # forward: deterministic kernels
+    for a, b_ in zip(res['exact'], res['split16']):
+        assert _rel(a, b_.double()) <= 1e-5
+    math_mode.reset()
+
+
+def test_split16_mode_other_skeletons_run_exact(dev):
+    """the split kernels are generated for the P2RNet skeleton; any other adjacency runs the exact kernels in either mode"""
+    import numpy as np
+    from pose2room_amd.p2rnet import gcn_op, math_mode
+    rng = np.random.RandomState(3)
+    K, Vj = 11, 25
+    A = np.zeros((K, Vj, Vj), dtype=np.float32)
+    for k in range(K):
+        for v in range(Vj):
+            A[k, v, (v + k) % Vj] = rng.uniform(0.2, 1.0)
+    tables = gcn_op.GraphTables(A)
+    assert not tables.gen3h and tables.pairs_c is None
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 32, Vj, generator=g).to(dev)
+    w = (torch.randn(K * 64, 64, generator=g) / 8).to(dev)
+    out = {}
+    for m in ('exact', 'split16'):
+        with math_mode.use(m):
+            out[m] = gcn_op.graph_conv(x, w, None, torch.tensor(A).to(dev), tables)
+    assert torch.equal(out['exact'], out['split16'])
+    math_mode.reset()

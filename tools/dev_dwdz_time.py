@@ -23,3 +23,6 @@ fn = lambda: _lib.check(_lib.lib().p2r_stgcn_tconv_weight_grad_dz(N, T, V, 3, _l
 print(f'weight_grad_dz {t(fn):.4f} ms')
 fn2 = lambda: _lib.check(_lib.lib().p2r_stgcn_tconv_weight_grad(N, T, V, 3, _lib.ptr(x), _lib.ptr(fin[2]), _lib.ptr(fin[3]), _lib.ptr(du), 256, _lib.ptr(part), _lib.ptr(bp), st), 'wg')
 print(f'weight_grad    {t(fn2):.4f} ms')
+word = torch.zeros(1, dtype=torch.int32, device=dev)
+fn3 = lambda: _lib.check(_lib.lib().p2r_stgcn_tconv_weight_grad_dz_amax(N, T, V, 3, _lib.ptr(x), _lib.ptr(fin), _lib.ptr(du), _lib.ptr(dh), _lib.ptr(m12), _lib.ptr(dz), 256, _lib.ptr(part), _lib.ptr(bp), _lib.ptr(word), st), 'wgdz_amax')
+print(f'weight_grad_dz_amax (split16 mode: + range word of dz) {t(fn3):.4f} ms; word {word.view(torch.float32).item():.4f} vs max |dz| {dz.abs().max().item():.4f}')
