@@ -54,7 +54,7 @@ _BASE = {
              'use_old_type_nms': False, 'per_class_proposal': True, 'conf_thresh': 0.05,
              'multi_mode': False, 'sample_cls': False},
     'demo': {'phase': 'full'},
-    'log': {'path': 'out/p2rnet'},
+    'log': {'path': 'out/p2rnet', 'save_weight_step': 50, 'vis_step': 10, 'print_step': 10},     # p2rnet_train.yaml:55-59
 }
 
 

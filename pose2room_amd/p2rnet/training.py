@@ -215,3 +215,94 @@ class Trainer(object):
         est_data = self.net(data)
         loss = self.net.module.loss(est_data, data)
         return _scalars(reduce_dict(loss))
+
+    def show_lr(self):
+        """models/training.py:17-23"""
+        lrs = [g['lr'] for g in self.optimizer.param_groups]
+        self.cfg.log_string('Current learning rates are: ' + str(lrs) + '.')
+
+    def eval_loss_parser(self, loss_recorder):
+        """models/training.py:45-51: the scalar the best checkpoint is chosen by"""
+        return loss_recorder['total'].avg
+
+    def visualize_step(self, *args, **kwargs):
+        """models/p2rnet/training.py:28-30: a no-op in the reference as well"""
+
+
+def train_epoch(cfg, epoch, trainer, dataloaders, log_board=None):
+    """One epoch over the 'train' and the 'val' loader -- mirror of the reference's train_epoch.py:8-58 (the caller of
+    the hot path): network mode per phase (`net.train(phase == 'train')` + `module.set_mode()`), sampler epoch under
+    DDP, `train_step` / `eval_step` per batch, loss meters synchronised over the ranks.  Returns the 'val' phase's
+    recorder dict {name: AverageMeter} like the reference.  `log_board` (TensorBoard in the reference: out of scope) is
+    any object with `update(loss, step_len, phase)`, or None."""
+    from .testing import LossRecorder
+    loss_recorder = None
+    for phase in ['train', 'val']:
+        dataloader = dataloaders[phase].dataloader
+        sampler = dataloaders[phase].sampler
+        batch_size = cfg.config[phase]['batch_size']
+        loss_recorder = LossRecorder(batch_size)
+        trainer.net.train(phase == 'train')
+        trainer.net.module.set_mode()
+        if cfg.config['device']['distributed']:
+            sampler.set_epoch(epoch)
+        cfg.log_string('-' * 100)
+        cfg.log_string('Switch Phase to %s.' % (phase))
+        cfg.log_string('-' * 100)
+        for it, data in enumerate(dataloader):
+            if phase == 'train':
+                loss = trainer.train_step(data)
+            else:
+                with torch.no_grad():       # (the reference builds the graph here too and drops it; same values)
+                    loss = trainer.eval_step(data)
+            if (it % cfg.config['log']['vis_step']) == 0:
+                trainer.visualize_step(epoch, phase, it, data)
+            loss_recorder.update_loss(loss)
+            if (it % cfg.config['log']['print_step']) == 0:
+                cfg.log_string('Process: Phase: %s. Epoch %d: %d/%d. Current loss: %s.'
+                               % (phase, epoch, it + 1, len(dataloader), str(loss)))
+                if log_board is not None:
+                    log_board.update(loss, cfg.config['log']['print_step'] * batch_size, phase)
+        loss_recorder.synchronize_between_processes(trainer.device)
+        cfg.log_string('=' * 100)
+        for loss_name, loss_value in loss_recorder.loss_recorder.items():
+            cfg.log_string('Currently the last %s loss (%s) is: %f' % (phase, loss_name, loss_value.avg))
+        cfg.log_string('=' * 100)
+    return loss_recorder.loss_recorder
+
+
+def train(cfg, trainer, scheduler, checkpoint, train_loader, val_loader, log_board=None, bnm_scheduler=None):
+    """Epoch loop -- mirror of train_epoch.py:60-105 (`bnm_scheduler`: the reference defines a BatchNorm-momentum
+    scheduler, models/optimizers.py:54-58, but its train.py never builds one; stepped here only when the caller passes it).  `checkpoint` is any object with `get('min_loss')`, `register_modules(**kw)` and
+    `save(name)` (the reference's CheckpointIO: file IO is out of scope, a dict-backed stand-in serves), or None."""
+    import time
+    start_epoch = scheduler.last_epoch
+    total_epochs = cfg.config['train']['epochs']
+    min_eval_loss = checkpoint.get('min_loss') if checkpoint is not None else None
+    dataloaders = {'train': train_loader, 'val': val_loader}
+    history = []
+    for epoch in range(start_epoch, total_epochs):
+        cfg.log_string('-' * 100)
+        cfg.log_string('Epoch (%d/%s):' % (epoch + 1, total_epochs))
+        trainer.show_lr()
+        if bnm_scheduler is not None:
+            bnm_scheduler.show_momentum()
+        start = time.time()
+        eval_loss_recorder = train_epoch(cfg, epoch + 1, trainer, dataloaders, log_board)
+        eval_loss = trainer.eval_loss_parser(eval_loss_recorder)
+        scheduler.step()
+        if bnm_scheduler is not None:
+            bnm_scheduler.step()
+        cfg.log_string('Epoch (%d/%s) Time elapsed: (%f).' % (epoch + 1, total_epochs, time.time() - start))
+        history.append(eval_loss)
+        if checkpoint is not None:
+            checkpoint.register_modules(epoch=epoch, min_loss=eval_loss)
+            if ((epoch % cfg.config['log']['save_weight_step']) == 0) or (epoch == total_epochs - 1):
+                checkpoint.save('last_%d' % (epoch))
+                cfg.log_string('Saved the latest checkpoint.')
+        if epoch == 0 or min_eval_loss is None or eval_loss < min_eval_loss:
+            if checkpoint is not None:
+                checkpoint.save('best')
+            min_eval_loss = eval_loss
+            cfg.log_string('Saved the best checkpoint.')
+    return history
