@@ -4,8 +4,8 @@
 A=$(realpath $1); N=${2:-2}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
 for i in $(seq $N); do
-  P2R_LIB_PATH=$A python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-microbench > gpurun_out/ab_A$i.json 2>/dev/null
-  python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-microbench > gpurun_out/ab_B$i.json 2>/dev/null
+  P2R_LIB_PATH=$A python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-microbench --no-split16 > gpurun_out/ab_A$i.json 2>/dev/null
+  python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-microbench --no-split16 > gpurun_out/ab_B$i.json 2>/dev/null
 done
 python - <<PY
 import json, glob
