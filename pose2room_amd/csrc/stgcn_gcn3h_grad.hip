@@ -161,13 +161,18 @@ __device__ __forceinline__ void d3_reduce(const f32x4 &h, const float (&dv)[6][4
     load_a(aS[(set) ^ 1], next, (wrap) ? ((ph + 1) & 3) : ph);                        \
     if ((piece) >= 0 && copy) dma_piece(piece);                                      \
   }
+#ifdef D3_NO_FENCE
+#define D3_FENCE
+#else
+#define D3_FENCE __builtin_amdgcn_sched_barrier(0);
+#endif
 #define D3_STEP(set, slot, ne, o0, c0, o1, c1, o2, c2, o3, c3, o4, c4, o5, c5)   \
   {                                                                              \
     float dv_[6][4];                                                             \
     d3_gather<ne, o0, o1, o2, o3, o4, o5>(xl, dv_);                              \
-    __builtin_amdgcn_sched_barrier(0);                                           \
+    D3_FENCE                                                                     \
     d3_mfma6(h, aS[set], bz[slot]);                                             \
-    __builtin_amdgcn_sched_barrier(0);                                           \
+    D3_FENCE                                                                     \
     d3_reduce<ne, c0, c1, c2, c3, c4, c5>(h, dv_, dcs_off);                      \
   }
 #define D3_CONT(ne, o0, c0, o1, c1, o2, c2, o3, c3, o4, c4, o5, c5)   \
