@@ -13,6 +13,7 @@
 #   noepi    no statistics / store epilogue (skipped at run time)
 #   nocs     no combine and split stages (the gathered values are only waited for)
 #   pure     nomfma + nolds + novisit + nodma: vector work, barriers and the epilogue only
+#   sgb      no fences around the MFMA groups; a sched_group_barrier pipeline 12 x (1 MFMA, 3 VALU) over each unit's region
 #   spread   the 12 MFMAs of a unit issued as 3 x 4 between the next unit's combine / split stages (numerics intact)
 set -e
 cd "$(dirname "$0")/.."
@@ -20,7 +21,7 @@ SRC=pose2room_amd/csrc
 make -s -C $SRC >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize"
 OTHERS=$(ls $SRC/*.o | grep -v stgcn_gcn3h_fwd.o)
-for v in ${VARIANTS:-base nolds nomfma novisit nodma nofence spread mix noepi nocs pure}; do
+for v in ${VARIANTS:-base nolds nomfma novisit nodma nofence spread mix noepi nocs pure sgb}; do
   d=tmp_ab/abl/$v; mkdir -p $d
   cp $SRC/stgcn_gcn3h_fwd.hip $SRC/gcn3h_sched_c.inc $d/
   python3 - "$v" $SRC/stgcn_gcn3h_body.h $d/stgcn_gcn3h_body.h $d/gcn3h_sched_c.inc <<'PY'
@@ -87,6 +88,14 @@ if v == 'mix':
     b2_[par] = __builtin_bit_cast(p2r_h8, h3_u4{r_[0], r_[1], r_[2], r_[3]});              \\
   }
 """ + s[b:]
+if v == 'sgb':
+    sub("    __builtin_amdgcn_sched_barrier(0);                        \\\n    h3_mfma12(acc[slot], aS[0], aS[1], b1_[par], b2_[par]);   \\\n    __builtin_amdgcn_sched_barrier(0);                        \\\n",
+        "    h3_mfma12(acc[slot], aS[0], aS[1], b1_[par], b2_[par]);   \\\n")
+    sub("    b2_[par] = __builtin_bit_cast(p2r_h8, h3_u4{r_[0], r_[1], r_[2], r_[3]});              \\\n",
+        "    b2_[par] = __builtin_bit_cast(p2r_h8, h3_u4{r_[0], r_[1], r_[2], r_[3]});              \\\n"
+        "    _Pragma(\"unroll\") for (int i_ = 0; i_ < 12; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, SGB_N, 0); } \\\n"
+        "    __builtin_amdgcn_sched_barrier(0);                                                    \\\n")
+    s = "#define SGB_N 3\n" + s
 if v == 'spread':
     sub("#define H3_END(pieces, pair0)", """#define H3_MX(part, slot, par)                                \\
   {                                                           \\
