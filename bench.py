@@ -488,13 +488,18 @@ def main():
         return trainer.train_step(dict(batch))
 
     verify = verify_bench_shape(trainer, batch)      # not timed, not part of the warm-up count
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     # Python's cyclic GC: the first full (generation-2) collection of a process walks every object torch and the
     # model have created -- a ~100 ms host pause that lands around the 11th step (measured, tools/step_times2.py).
     # Collect now and freeze the survivors so later collections only look at the objects of the steps themselves.
+    # The collection goes in front of the LAST warm-up step: the device sits idle under it and drops its clocks, and a
+    # timed region that starts right behind it pays 2-3 ms on its first step (per-step events: 43.2, 40.6, 40.8, ... ms);
+    # behind one more warm-up step it starts at the clocks the other steps run at.
     gc.collect()
     gc.freeze()
+    if args.warmup > 0:
+        step()
 
     def timed(run_step):
         """K steps between barrier + synchronize; also the per-step device time from events between the steps."""
