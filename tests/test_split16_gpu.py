@@ -445,3 +445,98 @@ def test_split16_mode_other_skeletons_run_exact(dev):
             out[m] = gcn_op.graph_conv(x, w, None, torch.tensor(A).to(dev), tables)
     assert torch.equal(out['exact'], out['split16'])
     math_mode.reset()
+
+
+@pytest.mark.parametrize("N,T", [(1, 16), (3, 48), (2, 256)])
+def test_split16_kernels_write_only_their_outputs(dev, N, T):
+    """every output of the split16 kernels (result tensors, statistics partials, weight / adjacency gradient partials)
+    sits in the middle of a larger buffer of sentinels: each kernel fills its output completely and touches nothing
+    around it (the entry points are called with the raw pointers, as a C caller would)"""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables, math_mode, tconv_op
+    lib = _lib.lib()
+    st = _lib.current_stream(dev)
+    GUARD, SENT = 4096, -12345.0
+
+    def guarded(shape):
+        n = 1
+        for s in shape:
+            n *= s
+        buf = torch.full((n + 2 * GUARD,), SENT, device=dev)
+        return buf, buf[GUARD:GUARD + n].view(shape)
+
+    def check(what, buf, out):
+        n = out.numel()
+        assert bool((buf[:GUARD] == SENT).all()) and bool((buf[GUARD + n:] == SENT).all()), what + ": wrote outside"
+        assert not bool((out == SENT).any()), what + ": output not filled"
+        assert bool(torch.isfinite(out).all()), what
+
+    A, x, w, b, imp, go = _gcn_case(N, T, 77 + T, 1e-3)
+    tables = gcn_op.GraphTables(A)
+    t = tables.on(dev)
+    K = A.shape[0]
+    W = w.view(K, 64, 64).to(dev)
+    Aeff = (torch.tensor(A, dtype=torch.float32) * imp).to(dev)
+    cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+    spf = gcn_op.SplitPlanes(*gcn_op.split_planes(W, tables.pairs_c))
+    spb = gcn_op.SplitPlanes(*gcn_op.split_planes(W.transpose(1, 2), tables.pairs_r))
+    spd = gcn_op.SplitPlanes(*gcn_op.split_planes_coef_grad(W))
+    x, dz = x.to(dev), go.to(dev)
+    xw, dw = math_mode.range_word(x), math_mode.range_word(dz)
+    bias_cv = torch.randn(64, V, device=dev)
+    shape = (N, 64, T, V)
+    nb = min(N * (T // 16), 256)
+    with torch.cuda.device(dev):
+        # graph conv forward + statistics
+        zb, z = guarded(shape)
+        pb, part = guarded((nb, 64, 3))
+        _lib.check(lib.p2r_stgcn_gcn3h_forward(N, T, V, K, cc.shape[0], _lib.ptr(x), _lib.ptr(spf.wh), _lib.ptr(spf.winv),
+                                               _lib.ptr(cc), _lib.ptr(bias_cv), _lib.ptr(z), _lib.ptr(part), None,
+                                               _lib.ptr(xw), st), "gcn3h_forward")
+        check("gcn3h forward", zb, z)
+        check("gcn3h forward statistics", pb, part)
+        # data gradient with a masked addend
+        add = torch.randn(shape, device=dev) * 1e-3
+        mask = (torch.rand(shape, device=dev) > 0.5).to(torch.uint8)
+        db, dx = guarded(shape)
+        _lib.check(lib.p2r_stgcn_gcn3h_data_gradient(N, T, V, K, cr.shape[0], _lib.ptr(dz), _lib.ptr(spb.wh),
+                                                     _lib.ptr(spb.winv), _lib.ptr(cr), _lib.ptr(add), _lib.ptr(mask),
+                                                     _lib.ptr(dx), _lib.ptr(dw), st), "gcn3h_data_gradient")
+        check("gcn3h data gradient", db, dx)
+        # weight gradient + bias table, adjacency gradient (partials per workgroup)
+        NB = 256
+        wb, wpart = guarded((NB, K, 64, 64))
+        bb, bpart = guarded((NB, 64, V))
+        _lib.check(lib.p2r_stgcn_gcn3h_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                   _lib.ptr(wpart), _lib.ptr(bpart), _lib.ptr(xw), _lib.ptr(dw), st),
+                   "gcn3h_weight_grad")
+        check("gcn3h weight gradient", wb, wpart)
+        check("gcn3h bias-table gradient", bb, bpart)
+        cb, cpart = guarded((NB, cr.shape[0], V))
+        _lib.check(lib.p2r_stgcn_gcn3h_coef_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(spd.wh),
+                                                 _lib.ptr(spd.winv), NB, _lib.ptr(cpart), _lib.ptr(xw), st),
+                   "gcn3h_coef_grad")
+        check("gcn3h adjacency gradient", cb, cpart)
+        # temporal conv: forward + statistics, data gradient + BatchNorm-backward sums
+        xs, W3, scale, shift, bias = (q.to(dev) for q in _tconv_inputs(N, T, 5 + T))
+        taps = tconv_op.SplitTaps(*tconv_op.split_taps(W3))
+        chunk = 64 if T % 64 == 0 else (32 if T % 32 == 0 else 16)
+        ob, out = guarded(shape)
+        sb, spart = guarded((N * (T // chunk), 64, 3))
+        _lib.check(lib.p2r_stgcn_tconvh_forward(N, T, V, _lib.ptr(xs), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(taps.wh),
+                                                _lib.ptr(taps.winv), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(spart), None,
+                                                None, None, None, st), "tconvh_forward")
+        check("tconvh forward", ob, out)
+        check("tconvh forward statistics", sb, spart)
+        fin = torch.stack([torch.zeros(64, device=dev), torch.ones(64, device=dev), scale, shift]).contiguous()
+        du = xs * 1e-3
+        uw = math_mode.range_word(du)
+        gb, gout = guarded(shape)
+        s2b, s2 = guarded((N * (T // chunk), 64, 2))
+        _lib.check(lib.p2r_stgcn_tconvh_forward(N, T, V, _lib.ptr(du), None, None, _lib.ptr(taps.wh), _lib.ptr(taps.winv),
+                                                None, _lib.ptr(gout), _lib.ptr(s2), None, _lib.ptr(xs), _lib.ptr(fin),
+                                                _lib.ptr(uw), st), "tconvh data gradient")
+        check("tconvh data gradient", gb, gout)
+        check("tconvh data gradient sums", s2b, s2)
+    math_mode.reset()
