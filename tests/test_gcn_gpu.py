@@ -439,3 +439,103 @@ def test_gcn3_adjacency_gradient(dev, N, T):
     want = torch.where(gi >= 0, dA.reshape(-1)[gi.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=dev))
     assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     assert (got[gi < 0] == 0).all()
+
+
+@pytest.mark.parametrize("N,T", [(1, 16), (3, 48), (2, 256)])
+def test_gcn3_tconv3_kernels_write_only_their_outputs(dev, N, T):
+    """the statically scheduled exact-fp32 kernels of the headline path (graph conv forward + statistics, data gradient
+    with masked addend and BatchNorm-backward sums, weight / bias-table / adjacency gradients, temporal conv forward and
+    data gradient, its weight gradient fused with the BatchNorm-backward apply pass): every output inside guard bands
+    of sentinels -- filled completely, nothing written outside (raw pointers, as a C caller passes them)"""
+    from pose2room_amd import _lib
+    from pose2room_amd.p2rnet import gcn_op, gcn_tables, tconv_op
+    from pose2room_amd.p2rnet.modules.stgcn_layers import Graph
+    lib = _lib.lib()
+    st = _lib.current_stream(dev)
+    GUARD, SENT, V = 4096, -12345.0, 53
+
+    def guarded(shape, dtype=torch.float32):
+        n = int(np.prod(shape))
+        buf = torch.full((n + 2 * GUARD,), SENT, device=dev, dtype=dtype)
+        return buf, buf[GUARD:GUARD + n].view(shape)
+
+    def check(what, buf, out):
+        n = out.numel()
+        assert bool((buf[:GUARD] == SENT).all()) and bool((buf[GUARD + n:] == SENT).all()), what + ": wrote outside"
+        assert not bool((out == SENT).any()), what + ": output not filled"
+        assert bool(torch.isfinite(out).all()), what
+
+    A = Graph().A
+    K = A.shape[0]
+    tables = gcn_op.GraphTables(A)
+    assert tables.gen3
+    t = tables.on(dev)
+    g = torch.Generator().manual_seed(31 + T)
+    shape = (N, 64, T, V)
+    x = torch.relu(torch.randn(shape, generator=g) + 0.3).to(dev)
+    dz = (torch.randn(shape, generator=g) * 1e-3).to(dev)
+    W = (torch.randn(K, 64, 64, generator=g) / 8).to(dev)
+    Aeff = (torch.tensor(A, dtype=torch.float32) * (1 + 0.1 * torch.randn(K, V, V, generator=g))).to(dev)
+    cc = gcn_tables.coefficients(Aeff, t['gidx_c']).contiguous()
+    cr = gcn_tables.coefficients(Aeff, t['gidx_r']).contiguous()
+    wpf, wpb = gcn_op.permute_planes(W), gcn_op.permute_planes(W.transpose(1, 2).contiguous())
+    bias_cv = torch.randn(64, V, device=dev)
+    nb = min(N * (T // 16), 256)
+    fin = torch.stack([torch.randn(64, device=dev) * 0.1, torch.rand(64, device=dev) + 0.5, torch.rand(64, device=dev) + 0.5,
+                       torch.randn(64, device=dev) * 0.1]).contiguous()
+    mask = (torch.rand(shape, device=dev) > 0.5).to(torch.uint8)
+    with torch.cuda.device(dev):
+        zb, z = guarded(shape)
+        pb, part = guarded((nb, 64, 3))
+        _lib.check(lib.p2r_stgcn_gcn3_forward(N, T, V, K, cc.shape[0], 0, _lib.ptr(x), _lib.ptr(wpf), _lib.ptr(cc),
+                                              _lib.ptr(bias_cv), None, _lib.ptr(z), _lib.ptr(part), None, None, None, None,
+                                              st), "gcn3_forward")
+        check("gcn3 forward", zb, z)
+        check("gcn3 forward statistics", pb, part)
+        add = torch.randn(shape, device=dev) * 1e-3
+        db, dx = guarded(shape)
+        sb, sums = guarded((nb, 64, 2))
+        _lib.check(lib.p2r_stgcn_gcn3_data_gradient_masked_addend(
+            N, T, V, K, cr.shape[0], _lib.ptr(dz), _lib.ptr(wpb), _lib.ptr(cr), _lib.ptr(add), _lib.ptr(mask), _lib.ptr(dx),
+            _lib.ptr(sums), _lib.ptr(x), _lib.ptr(mask), _lib.ptr(fin), st), "gcn3_data_gradient_masked_addend")
+        check("gcn3 data gradient", db, dx)
+        check("gcn3 data gradient sums", sb, sums)
+        NB = 256
+        wb, wpart = guarded((NB, K, 64, 64))
+        bb, bpart = guarded((NB, 64, V))
+        _lib.check(lib.p2r_stgcn_gcn3_weight_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(cr), NB,
+                                                  _lib.ptr(wpart), _lib.ptr(bpart), st), "gcn3_weight_grad")
+        check("gcn3 weight gradient", wb, wpart)
+        check("gcn3 bias-table gradient", bb, bpart)
+        cb, cpart = guarded((NB, cr.shape[0], V))
+        _lib.check(lib.p2r_stgcn_gcn3_coef_grad(N, T, V, K, cr.shape[0], _lib.ptr(x), _lib.ptr(dz), _lib.ptr(wpf), NB,
+                                                _lib.ptr(cpart), st), "gcn3_coef_grad")
+        check("gcn3 adjacency gradient", cb, cpart)
+        # temporal conv (3 taps): forward + statistics, data gradient + sums, weight gradient with the apply pass
+        W3 = (torch.randn(3, 64, 64, generator=g) / 8).to(dev)
+        Wp = tconv_op._permute_taps(W3)
+        scale, shift, bias = fin[2].contiguous(), fin[3].contiguous(), torch.randn(64, device=dev)
+        ob, out = guarded(shape)
+        s3b, s3 = guarded((nb, 64, 3))
+        _lib.check(lib.p2r_stgcn_tconv3_forward(N, T, V, 3, _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(Wp),
+                                                _lib.ptr(bias), _lib.ptr(out), _lib.ptr(s3), None, None, None, st),
+                   "tconv3_forward")
+        check("tconv3 forward", ob, out)
+        check("tconv3 forward statistics", s3b, s3)
+        Wpb = tconv_op._permute_taps(W3.flip(0).transpose(1, 2).contiguous())
+        gb, gout = guarded(shape)
+        s2b, s2 = guarded((nb, 64, 2))
+        _lib.check(lib.p2r_stgcn_tconv3_forward(N, T, V, 3, _lib.ptr(dz), None, None, _lib.ptr(Wpb), None, _lib.ptr(gout),
+                                                _lib.ptr(s2), None, _lib.ptr(x), _lib.ptr(fin), st), "tconv3 data gradient")
+        check("tconv3 data gradient", gb, gout)
+        check("tconv3 data gradient sums", s2b, s2)
+        m12 = (torch.randn(2, 64, device=dev) * 0.01).contiguous()
+        zb2, dzo = guarded(shape)
+        tb, tpart = guarded((NB, 64, 64, 3))
+        t2b, tbias = guarded((NB, 64))
+        _lib.check(lib.p2r_stgcn_tconv_weight_grad_dz(N, T, V, 3, _lib.ptr(x), _lib.ptr(fin), _lib.ptr(dz), _lib.ptr(add),
+                                                      _lib.ptr(m12), _lib.ptr(dzo), NB, _lib.ptr(tpart), _lib.ptr(tbias),
+                                                      st), "tconv_weight_grad_dz")
+        check("tconv weight gradient: dz", zb2, dzo)
+        check("tconv weight gradient: partials", tb, tpart)
+        check("tconv weight gradient: bias partials", t2b, tbias)
