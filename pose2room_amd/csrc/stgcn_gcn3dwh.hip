@@ -95,16 +95,24 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
 
   // this thread's items of the two tiles, (row, frame, 4-joint chunk): global offset (floats, the same for X and dZ) and
   // the LDS offsets (X: halves; dZ: floats)
+  // Recomputed for every tile from an opaque copy of the thread index, so that the compiler cannot keep these 28 values in
+  // registers through the tile's work: held for the whole kernel they pushed 148 registers into scratch INSIDE the unit
+  // loop (0.64 ms per launch; 24 spilled registers and 0.51 ms this way -- the integer arithmetic is ~100 instructions
+  // per tile).
   int xg[7], xo[7], zo[7];
   bool xlast[7];                                       // the chunk that holds joint 52 alone (53 = 13 x 4 + 1)
+  auto offsets = [&]() {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int item = i * NW * 64 + tid, row = item / (F * (XJ / 4)), rem = item % (F * (XJ / 4)), f = rem / (XJ / 4), ch = rem % (XJ / 4);
-    xg[i] = (int)((size_t)row * row_stride + f * V + 4 * ch);
-    xo[i] = (f * C + row) * (XSLOT / 2) + 4 * ch;
-    zo[i] = row * DZR + f * DZF + 4 * ch;
-    xlast[i] = 4 * ch + 4 > V;
-  }
+    for (int i = 0; i < 7; ++i) {
+      const int item = i * NW * 64 + tid_, row = item / (F * (XJ / 4)), rem = item % (F * (XJ / 4)), f = rem / (XJ / 4), ch = rem % (XJ / 4);
+      xg[i] = (int)((size_t)row * row_stride + f * V + 4 * ch);
+      xo[i] = (f * C + row) * (XSLOT / 2) + 4 * ch;
+      zo[i] = row * DZR + f * DZF + 4 * ch;
+      xlast[i] = 4 * ch + 4 > V;
+    }
+  };
   f32x4 acc[DW_MAXPL][2][4];
 #pragma unroll
   for (int s = 0; s < DW_MAXPL; ++s)
@@ -169,6 +177,7 @@ __device__ __forceinline__ void wave_main(const Params &p, float *lds, const flo
   int it = 0;
   for (int tile = tile_of(0); tile < p.total_tiles; tile = tile_of(++it)) {
     const size_t base = tile_base(tile);
+    offsets();
     fetch(x, base, xv);
     fetch(dz, base, zv);
     put_x();
