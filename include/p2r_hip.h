@@ -458,7 +458,9 @@ int p2r_embed_layer_backward(int N, int L, const float *g, const float *z, const
  * (gradient of the graph-conv bias table; the caller sums rows of a channel). */
 int p2r_colsum(int rows, int T, int V, const float *x, float *out_partial, void *stream);
 
-/* sum over the leading axis of per-workgroup partials: in [P][M] f32 -> out [M] (rows added in order: deterministic).
+/* sum over the leading axis of per-workgroup partials: in [P][M] f32 -> out [M], in a fixed order (deterministic): P < 32
+ * rows one after the other in two interleaved accumulators; P >= 32 sixteen strided partial sums (rows p = r, r + 16, ...)
+ * added in the order r = 0..15.
  * M % 4 == 0, in / out 16-byte aligned.  tr64 != 0: M = G * 4096 and every 64 x 64 block is written transposed
  * (the graph-conv weight-gradient kernel produces dW_k^T).  What `partials.sum(0)` did in the autograd wrappers. */
 int p2r_sum_leading(int P, long long M, const float *in, float *out, int tr64, void *stream);

@@ -564,12 +564,64 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(int P, long long M4, c
     o[(b + 0) * 64] = acc.x; o[(b + 1) * 64] = acc.y; o[(b + 2) * 64] = acc.z; o[(b + 3) * 64] = acc.w;
   }
 }
+
+// The same sum for many rows (P >= 32: the 256 per-workgroup partials of a step's weight gradients).  With one thread per
+// four outputs a thread walks all P rows on its own -- 32 dependent rounds of eight loads, and 12-44 workgroups for the
+// whole device at the shapes of a train step (20 us for 12-46 MB).  Here a workgroup owns 16 float4 columns and its 16
+// thread rows each take the rows p = ty, ty + 16, ...: two rounds of eight loads per thread, 16x the workgroups; the 16
+// partial sums meet in LDS and are added in the order ty = 0..15 (fixed: deterministic).
+__global__ __launch_bounds__(256) void sum_leading_rows_kernel(int P, long long M4, const float4 *__restrict__ in,
+                                                               float *__restrict__ out, int tr64) {
+  __shared__ float4 red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + tx;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < M4) {
+    int p = ty;
+    for (; p + 7 * 16 < P; p += 8 * 16) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld_stream(reinterpret_cast<const float *>(in + (size_t)(p + 16 * u) * M4 + i));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; p < P; p += 16) {
+      const float4 v = in[(size_t)p * M4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty != 0 || i >= M4) return;
+#pragma unroll
+  for (int r = 1; r < 16; ++r) {
+    const float4 v = red[r][tx];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (!tr64) {
+    reinterpret_cast<float4 *>(out)[i] = acc;
+  } else {
+    const long long e = 4 * i;                       // (block, a, b..b+3) -> (block, b.., a)
+    const long long blk = e >> 12;
+    const int a = (int)((e >> 6) & 63), b = (int)(e & 63);
+    float *o = out + (blk << 12) + a;
+    o[(b + 0) * 64] = acc.x; o[(b + 1) * 64] = acc.y; o[(b + 2) * 64] = acc.z; o[(b + 3) * 64] = acc.w;
+  }
+}
 }  // namespace
 
 extern "C" int p2r_sum_leading(int P, long long M, const float *in, float *out, int tr64, void *stream) {
   if (P <= 0 || M <= 0 || (M % 4) != 0 || ((uintptr_t)in % 16) != 0 || ((uintptr_t)out % 16) != 0) return P2R_EINVAL;
   if (tr64 && (M % 4096) != 0) return P2R_EINVAL;
   const long long M4 = M / 4;
+  if (P >= 32) {
+    const long long rblocks = (M4 + 15) / 16;
+    if (rblocks > 0x7fffffffLL) return P2R_EINVAL;
+    hipLaunchKernelGGL(sum_leading_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, p2r_stream(stream), P, M4,
+                       reinterpret_cast<const float4 *>(in), out, tr64);
+    P2R_LAUNCH_CHECK();
+    return P2R_OK;
+  }
   const long long blocks = (M4 + 255) / 256;
   if (blocks > 0x7fffffffLL) return P2R_EINVAL;
   hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)blocks), dim3(256), 0, p2r_stream(stream), P, M4,
